@@ -1,0 +1,110 @@
+"""ctypes binding of libdigitalearth_hip.so (C ABI in include/digital_earth.h).
+
+There is no CPU implementation behind this module: if the HIP library is missing, cannot be loaded, or finds no
+gfx950 device, the error is raised — nothing falls back to another code path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdigitalearth_hip.so")
+
+
+class DeParams(ctypes.Structure):
+    """`de_params` (include/digital_earth.h)."""
+    _fields_ = [
+        ("camera_pos", ctypes.c_float * 3), ("look_at", ctypes.c_float * 3), ("up", ctypes.c_float * 3),
+        ("fov", ctypes.c_float), ("aspect_scale", ctypes.c_float), ("sun_angle", ctypes.c_float),
+        ("sun_path_rot", ctypes.c_float), ("land_height_scale", ctypes.c_float), ("exposure", ctypes.c_float),
+        ("gamma", ctypes.c_float), ("selected_crf", ctypes.c_int32), ("vignette_strength", ctypes.c_float),
+        ("vignette_radius", ctypes.c_float), ("vignette_center", ctypes.c_float * 2), ("flags", ctypes.c_uint32),
+        ("fixed_wavelength", ctypes.c_float), ("topo_res_override", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+class DeCounters(ctypes.Structure):
+    """`de_counters` (include/digital_earth.h)."""
+    _fields_ = [("samples", ctypes.c_uint64), ("taps_r8", ctypes.c_uint64), ("taps_rgb8", ctypes.c_uint64),
+                ("sphere_steps", ctypes.c_uint64), ("tracking_steps", ctypes.c_uint64), ("vertices", ctypes.c_uint64),
+                ("rng_draws", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 9)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+DE_FLAG_FIXED_WAVELENGTH = 1 << 0
+DE_FLAG_CLAMP_SAMPLER = 1 << 1
+DE_FLAG_RAY_MARCHER = 1 << 2
+
+# name -> (restype, argtypes): every symbol include/digital_earth.h declares
+_P = ctypes.c_void_p
+SYMBOLS = {
+    "de_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_P)]),
+    "de_destroy": (ctypes.c_int, [_P]),
+    "de_upload_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "de_generate_texture": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int]),
+    "de_download_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint64]),
+    "de_texture_info": (ctypes.c_int, [_P, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3),
+    "de_upload_luts": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int]),
+    "de_set_params": (ctypes.c_int, [_P, ctypes.POINTER(DeParams)]),
+    "de_get_params": (ctypes.c_int, [_P, ctypes.POINTER(DeParams)]),
+    "de_reset": (ctypes.c_int, [_P]),
+    "de_accumulate": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]),
+    "de_fetch_image": (ctypes.c_int, [_P, _P]),
+    "de_render_to_image": (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
+    "de_fetch_hdr": (ctypes.c_int, [_P, _P]),
+    "de_upload_hdr": (ctypes.c_int, [_P, _P, ctypes.c_int]),
+    "de_current_spp": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
+    "de_set_current_spp": (ctypes.c_int, [_P, ctypes.c_int]),
+    "de_hdr_device_ptr": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
+    "de_set_stream": (ctypes.c_int, [_P, _P]),
+    "de_synchronize": (ctypes.c_int, [_P]),
+    "de_last_accumulate_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
+    "de_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(DeCounters)]),
+    "de_enable_counters": (ctypes.c_int, [_P, ctypes.c_int]),
+    "de_debug_samples": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_int, _P]),
+    "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),
+    "de_last_error": (ctypes.c_char_p, []),
+    "de_abi_version": (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdigitalearth_hip.so and type every entry point.  Raises NativeLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise NativeLibraryError("%s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class DigitalEarthError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libdigitalearth_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise DigitalEarthError(rc, load().de_last_error().decode(errors="replace"))

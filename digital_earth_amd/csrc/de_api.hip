@@ -1,0 +1,527 @@
+// de_api.hip — host side of libdigitalearth_hip.so: context, device memory, kernel launches, C ABI
+// (include/digital_earth.h).  No CPU fallback exists: every entry point needs a HIP device.
+#include "de_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+// single translation unit: the kernels are compiled together with the host API
+#include "render_kernel.hip"
+#include "aux_kernels.hip"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(DE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevTexture {
+    int w = 0, h = 0, ch = 0;
+    uint8_t* linear = nullptr;    // as uploaded: [h][w][ch]
+    uint32_t* packed = nullptr;   // footprint tiles (ch == 1) or rgbx dwords (ch == 3)
+    int tiles_x = 0, tiles_y = 0;
+    int packed_clamp = -1;        // address mode the packed copy was built with
+    bool set = false;
+};
+
+uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// tex.store into an rgba16f texture (renderer.py:213-216): binary32 -> binary16 -> binary32, RNE
+float quantize_f16(float f) {
+    uint32_t x = f2bits(f);
+    uint32_t sign = x & 0x80000000u, ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) return f;
+    if (ax >= 0x477ff000u) return bits2f(sign | 0x7f800000u);
+    if (ax < 0x33000001u) return bits2f(sign);
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x007fffffu) | 0x00800000u;
+    int shift = (e >= -14) ? 13 : (13 + (-14 - e));
+    uint32_t kept = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1u))) kept += 1;
+    float v = ldexpf((float)kept, e - 23 + shift);
+    return bits2f(f2bits(v) | sign);
+}
+float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    if (e == 31u) return bits2f(sign | 0x7f800000u | (m << 13));
+    if (e == 0u) return bits2f(f2bits((float)m * 0x1p-24f) | sign);
+    return bits2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+void default_params(de_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->camera_pos[0] = -15000000.0f; p->camera_pos[2] = 15000000.0f;   // earth_viewer.py:27
+    p->up[1] = 1.0f;
+    p->fov = (float)(27.0 * M_PI / 180.0 * 0.5);                        // renderer.py:50
+    p->aspect_scale = 1.0f; p->exposure = 2.5f; p->gamma = 1.0f;       // :51-53
+    p->sun_angle = (float)(60.0 * M_PI / 180.0);                       // :55
+    p->sun_path_rot = (float)(-45.0 * M_PI / 180.0);                   // :56
+    p->land_height_scale = 7800.0f;                                    // :58
+    p->vignette_strength = 0.9f; p->vignette_radius = 0.0f;            // :20-21
+    p->vignette_center[0] = 0.5f; p->vignette_center[1] = 0.5f;        // :22
+}
+
+// lib/OpenDRT.py:257-319,404 for the live module constants (Lp=100, gb=.12, c=1, fl=.005, dch=.35, EOTF=lin):
+// constant expressions, evaluated once in double and rounded to f32.
+void opendrt_consts(float* m, float* s, float* fl, float* ds, float* clamp_max, float* dch_s) {
+    const double Lp = 100.0, gb = 0.12, c = 1.0, flare = 0.005, dch = 0.35;
+    double ds_d = 100.0 / Lp, cm = ds_d * Lp / 100.0;
+    double px = 128.0 * log10(Lp) / log10(100.0) - 64.0, py = Lp / 100.0, gx = 0.18;
+    double gy = 11.696 / 100.0 * (1.0 + gb * log10(py) / log10(2.0));
+    double s0 = (gy + sqrt(gy * (4.0 * flare + gy))) / 2.0, m0 = (py + sqrt(py * (4.0 * flare + py))) / 2.0;
+    double ip = 1.0 / c;
+    double s_d = (px * gx * (pow(m0, ip) - pow(s0, ip))) / (px * pow(s0, ip) - gx * pow(m0, ip));
+    double m_d = pow(m0, ip) * (s_d + px) / px;
+    *m = (float)m_d; *s = (float)s_d; *fl = (float)flare; *ds = (float)ds_d; *clamp_max = (float)cm; *dch_s = (float)(dch / s_d);
+}
+
+}  // namespace
+
+struct de_ctx {
+    int device = 0;
+    int W = 0, H = 0;
+    de_params p;
+    bool params_dirty = true;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_valid = false;
+    DevTexture tex[DE_TEX_COUNT];
+    float* d_cie = nullptr;      // 441 x 2 x 3 (f16-quantised)
+    float* d_srgb2spec = nullptr;
+    float* d_o3 = nullptr;
+    float* d_crf = nullptr;      // [n][1024][3]
+    int n_crf = 0;
+    bool luts_set = false;
+    FrameConsts* d_fc = nullptr;
+    LambdaNode* d_nodes = nullptr;
+    float* d_node_val = nullptr;
+    float* d_hdr = nullptr;      // [H][W][3]
+    float* d_image = nullptr;    // (W, H, 3)
+    float* d_scratch = nullptr;  // (W, H, 3) / debug [H][W][4]
+    uint32_t* d_tiles = nullptr;
+    int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
+    unsigned long long* d_counters = nullptr;
+    bool count = false;
+    de_counters counters;
+    int current_spp = 0;
+};
+
+namespace {
+
+int ensure_packed(de_ctx* c, int slot, bool clamp) {
+    DevTexture& t = c->tex[slot];
+    if (t.packed_clamp == (clamp ? 1 : 0)) return DE_OK;
+    if (t.ch == 1) {
+        dim3 grid((unsigned)((t.w + 255) / 256), (unsigned)t.h);
+        hipLaunchKernelGGL(pack_r8_kernel, grid, dim3(256), 0, c->stream, t.linear, t.packed, t.w, t.h, t.tiles_x, clamp ? 1 : 0);
+    } else {
+        size_t n = (size_t)t.w * t.h;
+        hipLaunchKernelGGL(pack_rgb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, t.linear, t.packed, n);
+    }
+    HIP_TRY(hipGetLastError());
+    t.packed_clamp = clamp ? 1 : 0;
+    return DE_OK;
+}
+
+int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
+    DevTexture& t = c->tex[slot];
+    if (t.linear) { hipFree(t.linear); t.linear = nullptr; }
+    if (t.packed) { hipFree(t.packed); t.packed = nullptr; }
+    t.w = w; t.h = h; t.ch = ch; t.set = false; t.packed_clamp = -1;
+    HIP_TRY(hipMalloc(&t.linear, (size_t)w * h * ch));
+    if (ch == 1) {
+        t.tiles_x = (w + 7) / 8; t.tiles_y = (h + 3) / 4;
+        HIP_TRY(hipMalloc(&t.packed, (size_t)t.tiles_x * t.tiles_y * 32 * sizeof(uint32_t)));
+    } else {
+        t.tiles_x = t.tiles_y = 0;
+        HIP_TRY(hipMalloc(&t.packed, (size_t)w * h * sizeof(uint32_t)));
+    }
+    return DE_OK;
+}
+
+int run_setup(de_ctx* c) {
+    if (!c->params_dirty) return DE_OK;
+    SetupArgs s;
+    s.p = c->p;
+    opendrt_consts(&s.drt[0], &s.drt[1], &s.drt[2], &s.drt[3], &s.drt[4], &s.drt[5]);
+    s.W = c->W; s.H = c->H;
+    s.topo_w = c->tex[DE_TEX_TOPOGRAPHY].w > 0 ? c->tex[DE_TEX_TOPOGRAPHY].w : 1;
+    s.n_crf = c->n_crf;
+    s.cie.data = c->d_cie; s.cie.w = 441; s.cie.h = 2;
+    s.srgb2spec = c->d_srgb2spec; s.o3 = c->d_o3;
+    s.fc = c->d_fc; s.nodes = c->d_nodes; s.node_val = c->d_node_val;
+    hipLaunchKernelGGL(setup_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, s);
+    HIP_TRY(hipGetLastError());
+    c->params_dirty = false;
+    return DE_OK;
+}
+
+int build_tiles(de_ctx* c, int rank, int world) {
+    if (c->tiles_rank == rank && c->tiles_world == world && c->d_tiles) return DE_OK;
+    const int tx = c->W / 8, ty = c->H / 8;
+    std::vector<uint32_t> tiles;
+    tiles.reserve((size_t)tx * ty / world + tx);
+    for (int y = 0; y < ty; ++y)
+        for (int x = 0; x < tx; ++x)
+            if (world <= 1 || ((x + y) % world) == rank) tiles.push_back((uint32_t)(y * tx + x));
+    if (!c->d_tiles) HIP_TRY(hipMalloc(&c->d_tiles, (size_t)tx * ty * sizeof(uint32_t)));
+    if (!tiles.empty()) HIP_TRY(hipMemcpyAsync(c->d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // `tiles` goes out of scope
+    c->n_tiles = (int)tiles.size(); c->tiles_rank = rank; c->tiles_world = world;
+    return DE_OK;
+}
+
+int fill_render_args(de_ctx* c, RenderArgs* a) {
+    for (int i = 0; i < DE_TEX_COUNT; ++i)
+        if (!c->tex[i].set) return fail(DE_ERR_STATE, "all 7 textures must be uploaded or generated before rendering");
+    if (!c->luts_set) return fail(DE_ERR_STATE, "LUTs must be uploaded before rendering");
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    for (int i = 0; i < DE_TEX_COUNT; ++i) { int rc = ensure_packed(c, i, clamp); if (rc) return rc; }
+    int rc = run_setup(c);
+    if (rc) return rc;
+    auto r8 = [&](int slot) {
+        const DevTexture& t = c->tex[slot];
+        TexR8 o; o.data = t.packed; o.w = t.w; o.h = t.h; o.tiles_x = t.tiles_x; o.wf = (float)t.w; o.hf = (float)t.h;
+        return o;
+    };
+    auto rgb = [&](int slot) {
+        const DevTexture& t = c->tex[slot];
+        TexRGB o; o.data = t.packed; o.w = t.w; o.h = t.h; o.wf = (float)t.w; o.hf = (float)t.h;
+        return o;
+    };
+    a->fc = c->d_fc; a->nodes = c->d_nodes; a->node_val = c->d_node_val;
+    a->topo = r8(DE_TEX_TOPOGRAPHY); a->ocean = r8(DE_TEX_OCEAN); a->clouds = r8(DE_TEX_CLOUDS);
+    a->bathy = r8(DE_TEX_BATHYMETRY); a->emissive = r8(DE_TEX_EMISSIVE);
+    a->albedo = rgb(DE_TEX_ALBEDO); a->stars = rgb(DE_TEX_STARS);
+    a->hdr = c->d_hdr; a->W = c->W; a->H = c->H;
+    a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
+    a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
+    a->counters = c->d_counters; a->debug_out = c->d_scratch;
+    return DE_OK;
+}
+
+template <int MODE>
+void launch_render(de_ctx* c, const RenderArgs& a) {
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
+    dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
+    if (!clamp && !march) hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
+    else if (clamp && !march) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
+    else if (!clamp && march) hipLaunchKernelGGL((render_kernel<false, true, MODE>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((render_kernel<true, true, MODE>), grid, block, 0, c->stream, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* de_last_error(void) { return g_err.c_str(); }
+int de_abi_version(void) { return DE_ABI_VERSION; }
+
+int de_create(int device, int width, int height, de_ctx** out) {
+    if (!out) return fail(DE_ERR_INVALID, "out is null");
+    if (width <= 0 || height <= 0 || width % 16 || height % 8)
+        return fail(DE_ERR_INVALID, "image size must be a positive multiple of (16, 8) (renderer.py:46)");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(DE_ERR_NO_DEVICE, "no HIP device: libdigitalearth_hip has no CPU path");
+    if (device < 0 || device >= n_dev) return fail(DE_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    de_ctx* c = new de_ctx();
+    c->device = device; c->W = width; c->H = height;
+    default_params(&c->p);
+    memset(&c->counters, 0, sizeof(c->counters));
+    size_t npx = (size_t)width * height;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    c->own_stream = (e == hipSuccess);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc(&c->d_hdr, npx * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_image, npx * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_scratch, npx * 4 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_fc, sizeof(FrameConsts));
+    if (e == hipSuccess) e = hipMalloc(&c->d_nodes, DE_N_NODES * sizeof(LambdaNode));
+    if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_o3, 441 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_hdr, 0, npx * 3 * sizeof(float), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
+    if (e != hipSuccess) {
+        std::string msg = std::string("de_create: ") + hipGetErrorString(e);
+        de_destroy(c);
+        return fail(e == hipErrorOutOfMemory ? DE_ERR_NOMEM : DE_ERR_HIP, msg);
+    }
+    *out = c;
+    return DE_OK;
+}
+
+int de_destroy(de_ctx* c) {
+    if (!c) return DE_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr, c->d_image, c->d_scratch, c->d_tiles, c->d_counters};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return DE_OK;
+}
+
+int de_upload_texture(de_ctx* c, int slot, const uint8_t* texels, int w, int h, int channels) {
+    if (!c || slot < 0 || slot >= DE_TEX_COUNT || !texels || w <= 0 || h <= 0) return fail(DE_ERR_INVALID, "bad texture arguments");
+    const bool colour = (slot == DE_TEX_ALBEDO || slot == DE_TEX_STARS);
+    if (channels != (colour ? 3 : 1)) return fail(DE_ERR_INVALID, "albedo/stars take 3 channels, the grey maps 1");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = alloc_texture(c, slot, w, h, channels);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tex[slot].linear, texels, (size_t)w * h * channels, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tex[slot].set = true;
+    if (slot == DE_TEX_TOPOGRAPHY) c->params_dirty = true;
+    return DE_OK;
+}
+
+int de_generate_texture(de_ctx* c, int slot, int w, int h, uint32_t seed, int variant) {
+    if (!c || slot < 0 || slot >= DE_TEX_COUNT || w <= 0 || h <= 0) return fail(DE_ERR_INVALID, "bad texture arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool colour = (slot == DE_TEX_ALBEDO || slot == DE_TEX_STARS);
+    int rc = alloc_texture(c, slot, w, h, colour ? 3 : 1);
+    if (rc) return rc;
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    hipLaunchKernelGGL(synth_kernel, grid, dim3(256), 0, c->stream, c->tex[slot].linear, slot, w, h, seed, variant);
+    HIP_TRY(hipGetLastError());
+    c->tex[slot].set = true;
+    if (slot == DE_TEX_TOPOGRAPHY) c->params_dirty = true;
+    return DE_OK;
+}
+
+int de_download_texture(de_ctx* c, int slot, uint8_t* out, uint64_t out_bytes) {
+    if (!c || slot < 0 || slot >= DE_TEX_COUNT || !out || !c->tex[slot].set) return fail(DE_ERR_INVALID, "texture not set");
+    const DevTexture& t = c->tex[slot];
+    size_t n = (size_t)t.w * t.h * t.ch;
+    if (out_bytes < n) return fail(DE_ERR_INVALID, "output buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, t.linear, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_texture_info(de_ctx* c, int slot, int* w, int* h, int* ch) {
+    if (!c || slot < 0 || slot >= DE_TEX_COUNT) return fail(DE_ERR_INVALID, "bad slot");
+    if (w) *w = c->tex[slot].w;
+    if (h) *h = c->tex[slot].h;
+    if (ch) *ch = c->tex[slot].ch;
+    return DE_OK;
+}
+
+int de_upload_luts(de_ctx* c, const float* cie, const uint16_t* srgb2spec_f16, const float* o3, const float* crf, int n_crf) {
+    if (!c || !cie || !srgb2spec_f16 || !o3 || !crf || n_crf <= 0) return fail(DE_ERR_INVALID, "bad LUT arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> q(441 * 2 * 3), s(900), r((size_t)1024 * n_crf * 3);
+    for (int i = 0; i < 441 * 2 * 3; ++i) q[i] = quantize_f16(cie[i]);
+    for (int i = 0; i < 900; ++i) s[i] = half_to_float(srgb2spec_f16[i]);
+    for (int x = 0; x < 1024; ++x)
+        for (int y = 0; y < n_crf; ++y)
+            for (int ch = 0; ch < 3; ++ch) r[((size_t)y * 1024 + x) * 3 + ch] = crf[((size_t)x * n_crf + y) * 3 + ch];
+    if (c->d_crf) { hipFree(c->d_crf); c->d_crf = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_crf, r.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->d_cie, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_srgb2spec, s.data(), s.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_o3, o3, 441 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_crf, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_crf = n_crf; c->luts_set = true; c->params_dirty = true;
+    return DE_OK;
+}
+
+int de_set_params(de_ctx* c, const de_params* p) {
+    if (!c || !p) return fail(DE_ERR_INVALID, "null argument");
+    c->p = *p;
+    c->params_dirty = true;
+    return DE_OK;
+}
+int de_get_params(de_ctx* c, de_params* p) {
+    if (!c || !p) return fail(DE_ERR_INVALID, "null argument");
+    *p = c->p;
+    return DE_OK;
+}
+
+int de_reset(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_hdr, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    memset(&c->counters, 0, sizeof(c->counters));
+    c->current_spp = 0;
+    return DE_OK;
+}
+
+int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_world) {
+    if (!c || spp < 0 || tile_world < 1 || tile_rank < 0 || tile_rank >= tile_world) return fail(DE_ERR_INVALID, "bad accumulate arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = build_tiles(c, tile_rank, tile_world);
+    if (rc) return rc;
+    RenderArgs a;
+    rc = fill_render_args(c, &a);
+    if (rc) return rc;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.spp_begin = c->current_spp; a.spp_count = spp;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (spp > 0 && a.n_tiles > 0) {
+        if (c->count) launch_render<1>(c, a); else launch_render<0>(c, a);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timing_valid = true;
+    c->current_spp += spp;
+    return DE_OK;
+}
+
+int de_render_to_image(de_ctx* c, const float** device_image) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    if (!c->luts_set) return fail(DE_ERR_STATE, "LUTs must be uploaded before fetch_image");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = run_setup(c);
+    if (rc) return rc;
+    DisplayArgs d;
+    d.fc = c->d_fc; d.hdr = c->d_hdr; d.image = c->d_image;
+    d.crf.data = c->d_crf; d.crf.w = 1024; d.crf.h = c->n_crf;
+    d.W = c->W; d.H = c->H; d.samples = c->current_spp; d.clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) ? 1 : 0;
+    size_t npx = (size_t)c->W * c->H;
+    hipLaunchKernelGGL(display_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, d);
+    HIP_TRY(hipGetLastError());
+    if (device_image) *device_image = c->d_image;
+    return DE_OK;
+}
+
+int de_fetch_image(de_ctx* c, float* out) {
+    if (!out) return fail(DE_ERR_INVALID, "out is null");
+    int rc = de_render_to_image(c, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_image, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_fetch_hdr(de_ctx* c, float* out) {
+    if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t npx = (size_t)c->W * c->H;
+    hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->d_scratch, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_upload_hdr(de_ctx* c, const float* hdr, int spp) {
+    if (!c || !hdr || spp < 0) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t npx = (size_t)c->W * c->H;
+    std::vector<float> t(npx * 3);
+    for (int i = 0; i < c->W; ++i)
+        for (int j = 0; j < c->H; ++j)
+            for (int ch = 0; ch < 3; ++ch) t[((size_t)j * c->W + i) * 3 + ch] = hdr[((size_t)i * c->H + j) * 3 + ch];
+    HIP_TRY(hipMemcpyAsync(c->d_hdr, t.data(), npx * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->current_spp = spp;
+    return DE_OK;
+}
+int de_current_spp(de_ctx* c, int* spp) { if (!c || !spp) return fail(DE_ERR_INVALID, "null argument"); *spp = c->current_spp; return DE_OK; }
+int de_set_current_spp(de_ctx* c, int spp) { if (!c || spp < 0) return fail(DE_ERR_INVALID, "bad spp"); c->current_spp = spp; return DE_OK; }
+
+int de_hdr_device_ptr(de_ctx* c, void** ptr, uint64_t* n_floats) {
+    if (!c || !ptr) return fail(DE_ERR_INVALID, "null argument");
+    *ptr = c->d_hdr;
+    if (n_floats) *n_floats = (uint64_t)c->W * c->H * 3;
+    return DE_OK;
+}
+int de_set_stream(de_ctx* c, void* hip_stream) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return DE_OK;
+}
+int de_synchronize(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+int de_last_accumulate_ms(de_ctx* c, float* ms) {
+    if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
+    if (!c->timing_valid) return fail(DE_ERR_STATE, "no de_accumulate has been issued");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DE_OK;
+}
+int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }
+int de_get_counters(de_ctx* c, de_counters* out) {
+    if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof(*out));
+    out->samples = h[0]; out->taps_r8 = h[1]; out->taps_rgb8 = h[2]; out->sphere_steps = h[3];
+    out->tracking_steps = h[4]; out->vertices = h[5]; out->rng_draws = h[6];
+    return DE_OK;
+}
+
+int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
+    if (!c || !out || sample_index < 0) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = build_tiles(c, 0, 1);
+    if (rc) return rc;
+    RenderArgs a;
+    rc = fill_render_args(c, &a);
+    if (rc) return rc;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    a.spp_begin = sample_index; a.spp_count = 1;
+    launch_render<2>(c, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->d_scratch, (size_t)c->W * c->H * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_debug_math(de_ctx* c, int fn, const float* a, const float* b, float* out, uint64_t n) {
+    if (!c || !a || !out || fn < 0 || fn > 8) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&da, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&dout, n * sizeof(float)));
+    if (b) HIP_TRY(hipMalloc(&db, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(da, a, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(db, b, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, da, db, dout, (size_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(da); hipFree(dout); if (db) hipFree(db);
+    return DE_OK;
+}
+
+}  // extern "C"

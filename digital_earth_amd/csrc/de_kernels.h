@@ -1,0 +1,82 @@
+// de_kernels.h — device structures shared by the kernels and the host API (de_api.hip).
+#pragma once
+#include "de_device.h"
+#include "../../include/digital_earth.h"
+
+// Per-frame constants: everything the reference recomputes per pixel (or per launch) from scalar state that is
+// uniform over the image.  Filled ON THE DEVICE by setup_kernel with the contract arithmetic, so the values are the
+// ones a per-pixel evaluation would produce (renderer.py:270-302, pathtracer.py:332-337, lib/OpenDRT.py:257-319).
+struct FrameConsts {
+    vec3 cam_pos, d, du, dv;                 // get_cast_dir basis            renderer.py:272,276-277
+    float fov, aspect_ratio, aspect_scale;   //                               renderer.py:271-275
+    float inv_h_dummy;
+    vec3 light_dir;                          //                               renderer.py:301-302
+    float sun_cos_angle, sun_angular_radius; //                               renderer.py:297-300
+    float land_height_scale;
+    float normal_eps;                        // pi * planet_r / TOPO_W        pathtracer.py:20
+    float offset_scale;                      // 1 + 1e-4*scale/12000          pathtracer.py:421
+    float kn_log;                            // log(2*3000 + 1)               lib/volume_rendering_models.py:89
+    float max_dens_r, max_dens_m, max_dens_o;//                               pathtracer.py:336
+    CloudPhaseConsts cloud;
+    // display
+    float exposure_scale;                    // 2^exposure                    renderer.py:355
+    float gamma;
+    float crf_slice_v;                       //                               renderer.py:338
+    float vig_strength, vig_radius, vig_cx, vig_cy;
+    float drt_m, drt_s, drt_fl, drt_ds, drt_clamp_max, drt_dch_s;
+    vec3 drt_w;                              // normalised (rw, 1, bw)        lib/OpenDRT.py:369-370
+};
+
+// One node of spectrum_sample's bisection tree (lib/colour.py:24-39): 8 steps reach one of 256 leaves; an exact
+// tie stops early at an inner node.  Heap numbering: root 1, children 2n / 2n+1; index 0 = the fixed-wavelength
+// entry of BASELINE cfg1.  Everything path_tracer derives from the wavelength alone (pathtracer.py:332-343) is here.
+struct LambdaNode {
+    float wavelength;
+    float rx, ry, rz;        // CMF response                     lib/colour.py:40
+    float rcp_pdf;           //                                  lib/colour.py:42-46
+    float ext_r, ext_m, ext_o;
+    float sun_power, night_power, sun_irradiance;
+    float max_ext_rmo;       //                                  pathtracer.py:355
+    float c0, c1, c2;        // srgb_to_spectrum coefficients mix(lut[w], lut[w+1], f)   lib/colour.py:64-70
+    float s2s_valid;         // 1 if 0 < w < 299 else 0
+};
+#define DE_N_NODES 512
+
+struct RenderArgs {
+    const FrameConsts* fc;
+    const LambdaNode* nodes;
+    const float* node_val;        // [256] CDF value tested at inner node n (lib/colour.py:28)
+    TexR8 topo, ocean, clouds, bathy, emissive;
+    TexRGB albedo, stars;
+    float* hdr;                   // [H][W][3]
+    int W, H;
+    const uint32_t* tiles;        // owned 8x8 tiles (tile id = ty * tiles_x + tx)
+    int n_tiles, tiles_x;
+    uint32_t seed_lo, seed_hi;
+    int spp_begin, spp_count;
+    int fixed_wavelength;
+    unsigned long long* counters; // [8] when counting
+    float* debug_out;             // [H][W][4] when tracing single samples
+};
+
+struct SetupArgs {
+    de_params p;
+    int W, H;
+    int topo_w;
+    int n_crf;
+    TexF3 cie;
+    const float* srgb2spec;   // 300 x 3
+    const float* o3;          // 441
+    float drt[6];             // OpenDRT m, s, fl, ds, clamp_max, dch_s (host, double -> f32)
+    FrameConsts* fc;
+    LambdaNode* nodes;
+    float* node_val;
+};
+
+struct DisplayArgs {
+    const FrameConsts* fc;
+    const float* hdr;   // [H][W][3]
+    float* image;       // (W, H, 3)
+    TexF3 crf;
+    int W, H, samples, clamp;
+};

@@ -1,0 +1,164 @@
+// de_math.h — deterministic f32 elementary functions for the gfx950 kernels.
+//
+// Arithmetic contract: every function is a fixed sequence of correctly rounded binary32 operations
+// (+, -, *, /, sqrt, fma) plus floor and bit manipulation, so results do not depend on the device's
+// transcendental units (v_exp_f32 / v_log_f32 / v_sin_f32 are ~1 ulp and unspecified) and are reproducible
+// bit for bit on any IEEE-754 machine.  tests/test_gpu_math.py checks these against the CPU oracle's
+// independent statement of the same sequences.  Coefficients: tools/fit_f32_polys.py.
+//
+// The translation unit must be compiled with -ffp-contract=off (the only fused operations are the explicit
+// de_fma calls) and without fast-math; hipcc's default correctly rounded f32 divide/sqrt is relied upon.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DE_DEV __device__ __forceinline__
+
+DE_DEV float de_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DE_DEV uint32_t de_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+DE_DEV float de_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+DE_DEV float de_abs(float x) { return __builtin_fabsf(x); }
+DE_DEV float de_floor(float x) { return __builtin_floorf(x); }
+DE_DEV float de_sqrt(float x) { return __builtin_sqrtf(x); }  // correctly rounded; NaN for x < 0
+// comparison-defined min/max: a NaN in the second operand is dropped, a NaN in the first is returned
+DE_DEV float de_max(float a, float b) { return (b > a) ? b : a; }
+DE_DEV float de_min(float a, float b) { return (b < a) ? b : a; }
+DE_DEV float de_clamp(float x, float lo, float hi) { return de_min(de_max(x, lo), hi); }
+DE_DEV float de_saturate(float x) { return de_clamp(x, 0.0f, 1.0f); }
+
+#define DE_PI 0x1.921fb6p+1f
+#define DE_PIO2 0x1.921fb6p+0f
+#define DE_LN2_HI 0x1.63p-1f
+#define DE_LN2_LO -0x1.bd0106p-13f
+#define DE_LOG2E 0x1.715476p+0f
+#define DE_PIO2_HI 0x1.92p+0f
+#define DE_PIO2_MID 0x1.fb4p-12f
+#define DE_PIO2_LO 0x1.4442d2p-24f
+#define DE_2OPI 0x1.45f306p-1f
+#define DE_INF __builtin_inff()
+
+// e^x: x > 88 -> +inf, x < -87 -> 0, NaN -> NaN
+DE_DEV float de_exp(float x) {
+    float n = de_floor(de_fma(x, DE_LOG2E, 0.5f));
+    float r = de_fma(-n, DE_LN2_HI, x);
+    r = de_fma(-n, DE_LN2_LO, r);
+    float q = 0x1.6b9e2p-10f;
+    q = de_fma(q, r, 0x1.1239bep-7f);
+    q = de_fma(q, r, 0x1.5556d6p-5f);
+    q = de_fma(q, r, 0x1.555492p-3f);
+    q = de_fma(q, r, 0x1.fffffep-2f);
+    float p = de_fma(r * r, q, r);
+    p = p + 1.0f;
+    int ni = (int)n;
+    float res = p * de_u2f((uint32_t)(ni + 127) << 23);
+    res = (x > 88.0f) ? DE_INF : res;
+    res = (x < -87.0f) ? 0.0f : res;
+    return (x != x) ? x : res;
+}
+
+// natural log: 0 -> -inf, x < 0 -> NaN, +inf -> +inf; subnormals scaled first
+DE_DEV float de_log(float x) {
+    float xs = x;
+    int e = 0;
+    uint32_t ix = de_f2u(xs);
+    if (ix < 0x00800000u) { xs = xs * 8388608.0f; ix = de_f2u(xs); e = -23; }
+    e += (int)(ix >> 23) - 127;
+    float f = de_u2f((ix & 0x007fffffu) | 0x3f800000u);
+    if (f > 0x1.6a09e6p+0f) { f = f * 0.5f; e += 1; }
+    f = f - 1.0f;
+    float p = 0x1.16d79ep-4f;
+    p = de_fma(p, f, -0x1.dfb3a4p-4f);
+    p = de_fma(p, f, 0x1.e69804p-4f);
+    p = de_fma(p, f, -0x1.fbdbap-4f);
+    p = de_fma(p, f, 0x1.2338e2p-3f);
+    p = de_fma(p, f, -0x1.555e68p-3f);
+    p = de_fma(p, f, 0x1.99a4b4p-3f);
+    p = de_fma(p, f, -0x1.000002p-2f);
+    p = de_fma(p, f, 0x1.555548p-2f);
+    float f2 = f * f;
+    float fe = (float)e;
+    float y = (f * f2) * p;
+    y = de_fma(fe, DE_LN2_LO, y);
+    y = de_fma(-0.5f, f2, y);
+    float z = f + y;
+    float res = de_fma(fe, DE_LN2_HI, z);
+    res = (x == DE_INF) ? x : res;
+    res = (x == 0.0f) ? -DE_INF : res;
+    return (x != x || x < 0.0f) ? __builtin_nanf("") : res;
+}
+
+DE_DEV void de_sincos(float x, float* s_out, float* c_out) {
+    float k = de_floor(de_fma(x, DE_2OPI, 0.5f));
+    float r = de_fma(-k, DE_PIO2_HI, x);
+    r = de_fma(-k, DE_PIO2_MID, r);
+    r = de_fma(-k, DE_PIO2_LO, r);
+    int q = ((int)k) & 3;
+    float r2 = r * r;
+    float ps = 0x1.6cca94p-19f;
+    ps = de_fma(ps, r2, -0x1.a00f5ap-13f);
+    ps = de_fma(ps, r2, 0x1.111108p-7f);
+    ps = de_fma(ps, r2, -0x1.555556p-3f);
+    float sn = de_fma(r * r2, ps, r);
+    float pc = -0x1.241daap-22f;
+    pc = de_fma(pc, r2, 0x1.a010dap-16f);
+    pc = de_fma(pc, r2, -0x1.6c16b8p-10f);
+    pc = de_fma(pc, r2, 0x1.555556p-5f);
+    float cs = de_fma(r2 * r2, pc, de_fma(-0.5f, r2, 1.0f));
+    float s = (q & 1) ? cs : sn;
+    float c = (q & 1) ? sn : cs;
+    if (q & 2) s = -s;
+    if ((q + 1) & 2) c = -c;
+    *s_out = s;
+    *c_out = c;
+}
+DE_DEV float de_sin(float x) { float s, c; de_sincos(x, &s, &c); return s; }
+DE_DEV float de_cos(float x) { float s, c; de_sincos(x, &s, &c); return c; }
+
+// atan2(y, x) in (-pi, pi]; atan2(0, 0) := 0
+DE_DEV float de_atan2(float y, float x) {
+    float ax = de_abs(x), ay = de_abs(y);
+    bool swap = ay > ax;
+    float mx = swap ? ay : ax;
+    float mn = swap ? ax : ay;
+    float a = mn / mx;
+    float s = a * a;
+    float p = -0x1.d668cp-10f;
+    p = de_fma(p, s, 0x1.65b58ap-7f);
+    p = de_fma(p, s, -0x1.feccc6p-6f);
+    p = de_fma(p, s, 0x1.dabbfap-5f);
+    p = de_fma(p, s, -0x1.582c3cp-4f);
+    p = de_fma(p, s, 0x1.c09542p-4f);
+    p = de_fma(p, s, -0x1.242104p-3f);
+    p = de_fma(p, s, 0x1.9991e4p-3f);
+    p = de_fma(p, s, -0x1.55553ep-2f);
+    float r = de_fma(a * s, p, a);
+    if (swap) r = DE_PIO2 - r;
+    if (x < 0.0f) r = DE_PI - r;
+    if (y < 0.0f) r = -r;
+    return (mx == 0.0f) ? 0.0f : r;
+}
+
+// asin, argument clamped to [-1, 1]
+DE_DEV float de_asin(float x) {
+    float ax = de_abs(x);
+    if (ax > 1.0f) ax = 1.0f;
+    bool big = ax > 0.5f;
+    float s = big ? (1.0f - ax) * 0.5f : ax * ax;
+    float t = big ? de_sqrt(s) : ax;
+    float p = 0x1.3513acp-5f;
+    p = de_fma(p, s, 0x1.d3dfe8p-7f);
+    p = de_fma(p, s, 0x1.04f064p-5f);
+    p = de_fma(p, s, 0x1.6ca29p-5f);
+    p = de_fma(p, s, 0x1.3338d6p-4f);
+    p = de_fma(p, s, 0x1.55554cp-3f);
+    float r = de_fma(t * s, p, t);
+    if (big) r = de_fma(-2.0f, r, DE_PIO2);
+    r = (x < 0.0f) ? -r : r;
+    return (x != x) ? x : r;
+}
+
+DE_DEV float de_pow(float a, float b) {
+    if (b == 0.0f) return 1.0f;
+    if (b == 1.0f) return a;
+    return de_exp(b * de_log(a));
+}

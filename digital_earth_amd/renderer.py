@@ -1,0 +1,395 @@
+"""`Renderer` — the host-side operator API of the reference (renderer.py:15-401), bound to the gfx950 library.
+
+Method and attribute names, argument meaning and call order are the reference's:
+
+    r = Renderer(image_res=(1920, 1080), up=(0, 1, 0))      # renderer.py:17
+    r.set_camera_pos(x, y, z); r.set_look_at(...)            # :225-266
+    r.copy_textures()                                        # :136
+    r.accumulate()                                           # :371   (1 sample per pixel, current_spp += 1)
+    img = r.fetch_image()                                    # :382   (W, H, 3) float32 in [0, 1]
+    r.fov[None] = 0.2                                        # scalar fields keep Taichi's [None] indexing
+
+All device work happens in libdigitalearth_hip.so through ctypes (digital_earth_amd/_native.py).  There is no
+Taichi and no CPU implementation in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _native, luts, textures as tex
+from ._native import DeParams, DeCounters, check
+
+
+class _ScalarField:
+    """Stand-in for a 0-d ti.field: `field[None]` reads, `field[None] = v` writes (earth_viewer.py:191-199,308-314)."""
+
+    def __init__(self, owner, name, cast):
+        self._owner, self._name, self._cast = owner, name, cast
+
+    def __getitem__(self, key):
+        return self._cast(getattr(self._owner._params, self._name))
+
+    def __setitem__(self, key, value):
+        setattr(self._owner._params, self._name, self._cast(value))
+        self._owner._push_params()
+
+
+class _VectorField:
+    def __init__(self, owner, name):
+        self._owner, self._name = owner, name
+
+    def __getitem__(self, key):
+        return np.array(list(getattr(self._owner._params, self._name)), dtype=np.float32)
+
+    def __setitem__(self, key, value):
+        arr = getattr(self._owner._params, self._name)
+        for i in range(3):
+            arr[i] = float(value[i])
+        self._owner._push_params()
+
+
+class Renderer:
+    """GPU implementation of the reference `Renderer` (renderer.py:15-401).
+
+    Extra keyword arguments (no reference counterpart):
+      device          HIP device index (one context = one GPU)
+      texture_source  "auto": image files from `texture_dir` when present, else synthetic stand-ins;
+                      "files": image files only (FileNotFoundError like the reference when absent);
+                      "synthetic": procedural maps generated on the GPU (the reference ships no maps, README.md:31-32);
+                      "constant": 1x1 maps (BASELINE cfg1: flat albedo, no topography, no clouds)
+      texture_quality 0/1/2 — lib/textures.py:1 (resolutions of the tier are used for synthetic maps too)
+      texture_size    override (w, h) for every synthetic map (tests)
+      cloud_heavy     synthetic cloud variant of BASELINE cfg4
+      seed            base seed of the per-sample RNG streams
+    """
+
+    def __init__(self, image_res, up, device=0, texture_source="auto", texture_dir=None,
+                 texture_quality=tex.TEXTURE_QUALITY, texture_size=None, cloud_heavy=False, seed=0,
+                 synth_seed=tex.SYNTH_SEED):
+        self._lib = _native.load()
+        self.image_res = (int(image_res[0]), int(image_res[1]))
+        self.aspect_ratio = image_res[0] / image_res[1]                  # renderer.py:19
+        self.current_spp = 0                                             # :23
+        self.seed = int(seed)
+        self.tile_rank, self.tile_world = 0, 1
+        self._h = ctypes.c_void_p()
+        check(self._lib.de_create(int(device), self.image_res[0], self.image_res[1], ctypes.byref(self._h)))
+        self._params = DeParams()
+        check(self._lib.de_get_params(self._h, ctypes.byref(self._params)))   # reference defaults, renderer.py:20-22,49-58
+
+        self.fov = _ScalarField(self, "fov", float)                      # :27
+        self.aspect_scale = _ScalarField(self, "aspect_scale", float)    # :28
+        self.exposure = _ScalarField(self, "exposure", float)            # :30
+        self.selected_crf = _ScalarField(self, "selected_crf", int)      # :31
+        self.gamma = _ScalarField(self, "gamma", float)                  # :33
+        self.sun_angle = _ScalarField(self, "sun_angle", float)          # :36
+        self.sun_path_rot = _ScalarField(self, "sun_path_rot", float)    # :37
+        self.camera_pos = _VectorField(self, "camera_pos")               # :39
+        self.look_at = _VectorField(self, "look_at")                     # :40
+        self.up = _VectorField(self, "up")                               # :41
+
+        self.set_up(*up)                                                 # :49
+        self.set_fov(np.radians(27.) * 0.5)                              # :50
+        self.set_aspect_scale(1.0)
+        self.set_exposure(2.5)
+        self.set_gamma(1.0)
+        self.set_crf(0)
+        self.set_sun_angle(np.radians(60.0))
+        self.set_sun_path_rot(np.radians(-45.0))
+
+        # textures (renderer.py:60-94): staged here, sent to the device by copy_textures()
+        self._texture_plan = self._plan_textures(texture_source, texture_dir, texture_quality, texture_size,
+                                                 cloud_heavy, synth_seed)
+        self._textures_copied = False
+
+        # LUTs (renderer.py:96-134)
+        self.crf_names = []
+        crf_array = self.load_crfs()
+        self.crf_lut_res = (1024, len(self.crf_names))
+        self._luts = (luts.load_cie(), luts.load_srgb2spec(), luts.load_o3(), crf_array)
+        self.set_crf_count(self.crf_lut_res[1])
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.de_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ attributes kept from the reference
+    @property
+    def vignette_strength(self):
+        return self._params.vignette_strength
+
+    @vignette_strength.setter
+    def vignette_strength(self, v):
+        self._params.vignette_strength = float(v)
+        self._push_params()
+
+    @property
+    def vignette_radius(self):
+        return self._params.vignette_radius
+
+    @vignette_radius.setter
+    def vignette_radius(self, v):
+        self._params.vignette_radius = float(v)
+        self._push_params()
+
+    @property
+    def vignette_center(self):
+        return [self._params.vignette_center[0], self._params.vignette_center[1]]
+
+    @vignette_center.setter
+    def vignette_center(self, v):
+        self._params.vignette_center[0], self._params.vignette_center[1] = float(v[0]), float(v[1])
+        self._push_params()
+
+    @property
+    def land_height_scale(self):
+        return self._params.land_height_scale
+
+    @land_height_scale.setter
+    def land_height_scale(self, v):
+        self._params.land_height_scale = float(v)
+        self._push_params()
+
+    @property
+    def color_buffer(self):
+        """HDR accumulation as a (W, H, 3) float32 array (renderer.py:25,330)."""
+        return self.fetch_hdr()
+
+    def _push_params(self):
+        check(self._lib.de_set_params(self._h, ctypes.byref(self._params)))
+
+    # ------------------------------------------------------------------ textures
+    def _plan_textures(self, source, texture_dir, quality, size, cloud_heavy, synth_seed):
+        table = tex.texture_table(quality)
+        if source in ("auto", "files"):
+            d = texture_dir or tex.find_texture_dir()
+            have = d is not None and all(os.path.exists(os.path.join(d, table[s][0])) for s in table)
+            if have:
+                return [("file", s, os.path.join(d, table[s][0])) for s in range(7)]
+            if source == "files":
+                raise FileNotFoundError("texture files %s not found in %r (the reference expects them under textures/, "
+                                        "README.md:31-32)" % ([table[s][0] for s in table], d))
+            source = "synthetic"
+        if source == "synthetic":
+            plan = []
+            for s in range(7):
+                w, h = size if size is not None else table[s][1]
+                plan.append(("synthetic", s, (int(w), int(h), int(synth_seed), 1 if cloud_heavy else 0)))
+            return plan
+        if source == "constant":
+            return [("array", s, tex.constant_texels(s, (128, 128, 128) if s == tex.ALBEDO else 0)) for s in range(7)]
+        raise ValueError("texture_source must be auto, files, synthetic or constant")
+
+    def set_texture(self, slot, texels):
+        """Replace one map by a uint8 array [height][width][channels] (row 0 = south)."""
+        self._texture_plan[slot] = ("array", slot, np.ascontiguousarray(texels, dtype=np.uint8))
+        if self._textures_copied:
+            self._copy_one(self._texture_plan[slot])
+
+    def _copy_one(self, item):
+        kind, slot, arg = item
+        if kind == "synthetic":
+            w, h, seed, variant = arg
+            check(self._lib.de_generate_texture(self._h, slot, w, h, seed, variant))
+            return
+        arr = tex.load_image_texels(arg, tex.SLOT_CHANNELS[slot]) if kind == "file" else arg
+        h, w, ch = arr.shape
+        check(self._lib.de_upload_texture(self._h, slot, arr.ctypes.data, w, h, ch))
+
+    def copy_textures(self):
+        """renderer.py:136-145 — the nine copy_* upload kernels (7 maps + CIE + CRF)."""
+        for item in self._texture_plan:
+            self._copy_one(item)
+        cie, s2s, o3, crf = self._luts
+        check(self._lib.de_upload_luts(self._h, cie.ctypes.data, s2s.ctypes.data, o3.ctypes.data, crf.ctypes.data,
+                                       crf.shape[1]))
+        self._textures_copied = True
+
+    def download_texture(self, slot):
+        w, h, ch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self._lib.de_texture_info(self._h, slot, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)))
+        out = np.zeros((h.value, w.value, ch.value), dtype=np.uint8)
+        check(self._lib.de_download_texture(self._h, slot, out.ctypes.data, out.nbytes))
+        return out
+
+    def load_crfs(self):
+        """renderer.py:147-167 — (1024, n, 3) float32; fills self.crf_names (Neutral.rf first, then sorted: Q10)."""
+        names, arr = luts.load_crfs()
+        self.crf_names = list(names)
+        return arr
+
+    # ------------------------------------------------------------------ setters, renderer.py:224-266
+    def set_camera_pos(self, x, y, z):
+        self._params.camera_pos[0], self._params.camera_pos[1], self._params.camera_pos[2] = float(x), float(y), float(z)
+        self._push_params()
+
+    def set_up(self, x, y, z):
+        v = np.array([x, y, z], dtype=np.float32)
+        v = v / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])      # ti.Vector.normalized() in f32
+        self._params.up[0], self._params.up[1], self._params.up[2] = float(v[0]), float(v[1]), float(v[2])
+        self._push_params()
+
+    def set_look_at(self, x, y, z):
+        self._params.look_at[0], self._params.look_at[1], self._params.look_at[2] = float(x), float(y), float(z)
+        self._push_params()
+
+    def set_fov(self, fov):
+        self._params.fov = float(fov)
+        self._push_params()
+
+    def set_aspect_scale(self, scale):
+        self._params.aspect_scale = float(scale)
+        self._push_params()
+
+    def set_exposure(self, exposure):
+        self._params.exposure = float(exposure)
+        self._push_params()
+
+    def set_gamma(self, gam):
+        self._params.gamma = float(gam)
+        self._push_params()
+
+    def set_crf(self, index):
+        self._params.selected_crf = int(index)
+        self._push_params()
+
+    def set_crf_count(self, num):
+        self._crf_count = int(num)       # the device takes the count from the uploaded CRF array (renderer.py:257)
+
+    def set_sun_angle(self, ang):
+        self._params.sun_angle = float(ang)
+        self._push_params()
+
+    def set_sun_path_rot(self, ang):
+        self._params.sun_path_rot = float(ang)
+        self._push_params()
+
+    # extensions of the scalar state (include/digital_earth.h: de_params.flags)
+    def set_fixed_wavelength(self, nm):
+        """BASELINE cfg1: trace a single wavelength instead of sampling one per path (None to disable)."""
+        if nm is None:
+            self._params.flags &= ~_native.DE_FLAG_FIXED_WAVELENGTH
+        else:
+            self._params.flags |= _native.DE_FLAG_FIXED_WAVELENGTH
+            self._params.fixed_wavelength = float(nm)
+        self._push_params()
+
+    def set_flag(self, flag, on):
+        if on:
+            self._params.flags |= flag
+        else:
+            self._params.flags &= ~flag
+        self._push_params()
+
+    def set_integrator(self, name):
+        """'path_tracer' (pathtracer.py:316, what the reference runs) or 'ray_marcher' (pathtracer.py:544)."""
+        if name not in ("path_tracer", "ray_marcher"):
+            raise ValueError(name)
+        self.set_flag(_native.DE_FLAG_RAY_MARCHER, name == "ray_marcher")
+
+    def set_topo_res_override(self, res):
+        self._params.topo_res_override = int(res)
+        self._push_params()
+
+    def set_tile_partition(self, rank, world):
+        """Multi-GPU: this context renders only the 8x8 tiles (tx, ty) with (tx + ty) % world == rank."""
+        if not (0 <= rank < world):
+            raise ValueError("rank %d not in [0, %d)" % (rank, world))
+        self.tile_rank, self.tile_world = int(rank), int(world)
+
+    # ------------------------------------------------------------------ frame loop, renderer.py:367-384
+    def reset_framebuffer(self):
+        self.current_spp = 0
+        check(self._lib.de_reset(self._h))
+
+    def accumulate(self, spp=1):
+        """renderer.py:371-380, `spp` times in one launch (the reference's accumulate() is spp = 1)."""
+        if not self._textures_copied:
+            self.copy_textures()
+        check(self._lib.de_accumulate(self._h, int(spp), self.seed, self.tile_rank, self.tile_world))
+        self.current_spp += int(spp)
+
+    def fetch_image(self):
+        """renderer.py:382-384 — display transform of the accumulation; (W, H, 3) float32 in [0, 1]."""
+        if not self._textures_copied:
+            self.copy_textures()
+        out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
+        check(self._lib.de_fetch_image(self._h, out.ctypes.data))
+        return out
+
+    def fetch_hdr(self):
+        out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
+        check(self._lib.de_fetch_hdr(self._h, out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ measurement / plumbing
+    def synchronize(self):
+        check(self._lib.de_synchronize(self._h))
+
+    def last_accumulate_ms(self):
+        ms = ctypes.c_float()
+        check(self._lib.de_last_accumulate_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def enable_counters(self, on=True):
+        check(self._lib.de_enable_counters(self._h, 1 if on else 0))
+
+    def counters(self):
+        c = DeCounters()
+        check(self._lib.de_get_counters(self._h, ctypes.byref(c)))
+        return c.as_dict()
+
+    def hdr_device_pointer(self):
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        check(self._lib.de_hdr_device_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def set_stream(self, hip_stream_handle):
+        check(self._lib.de_set_stream(self._h, ctypes.c_void_p(hip_stream_handle)))
+
+    def upload_hdr(self, hdr, spp):
+        """Load an accumulation state ((W, H, 3) float32 sums, sample count) — resume of a progressive render."""
+        hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+        if hdr.shape != (self.image_res[0], self.image_res[1], 3):
+            raise ValueError("hdr must have shape (W, H, 3)")
+        check(self._lib.de_upload_hdr(self._h, hdr.ctypes.data, int(spp)))
+        self.current_spp = int(spp)
+
+    def set_current_spp(self, spp):
+        self.current_spp = int(spp)
+        check(self._lib.de_set_current_spp(self._h, int(spp)))
+
+    def debug_samples(self, sample_index):
+        """Per pixel [H][W]: radiance, wavelength, RNG draws, vertices of sample `sample_index` (not accumulated)."""
+        if not self._textures_copied:
+            self.copy_textures()
+        out = np.empty((self.image_res[1], self.image_res[0], 4), dtype=np.float32)
+        check(self._lib.de_debug_samples(self._h, self.seed, int(sample_index), out.ctypes.data))
+        return out
+
+    def debug_math(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.empty_like(a)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            bp = b.ctypes.data
+        check(self._lib.de_debug_math(self._h, int(fn), a.ctypes.data, bp, out.ctypes.data, a.size))
+        return out
+
+    @staticmethod
+    def to_vec3u(c):                                                     # renderer.py:386-393
+        return (np.clip(np.asarray(c, dtype=np.float32), 0.0, 1.0) * 255).astype(np.uint8)
+
+    @staticmethod
+    def to_vec3(c):                                                      # renderer.py:395-401
+        return np.asarray(c, dtype=np.float32) / 255.0

@@ -1,0 +1,162 @@
+/* digital_earth.h — C ABI of libdigitalearth_hip.so (MI355X / gfx950).
+ *
+ * The reference (AntonioFerreras/Digital-Earth) has no FFI layer: its "operator API" for the hot path is
+ * the Python class `Renderer` (renderer.py:15-401), whose @ti.kernel methods are the device boundary.
+ * Each entry point below replaces one group of those methods; the Python `Renderer` in
+ * digital_earth_amd/renderer.py binds them through ctypes.
+ *
+ * Conventions: every function returns 0 on success or a negative DE_ERR_* code and never throws;
+ * de_last_error() returns a thread-local message for the last failure.  The caller owns every host
+ * pointer; the library owns all device memory.  One context = one GPU = one HIP stream; calls on one
+ * context are not thread-safe (the reference is single-threaded, earth_viewer.py:183-318).
+ * There is no CPU fallback: de_create fails with DE_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DIGITAL_EARTH_H
+#define DIGITAL_EARTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DE_ABI_VERSION 1
+
+enum {
+    DE_OK = 0,
+    DE_ERR_INVALID = -1,   /* bad argument */
+    DE_ERR_NO_DEVICE = -2, /* no HIP device / wrong architecture */
+    DE_ERR_HIP = -3,       /* a HIP runtime call failed (message in de_last_error) */
+    DE_ERR_STATE = -4,     /* call order violated (e.g. accumulate before textures/LUTs are uploaded) */
+    DE_ERR_NOMEM = -5
+};
+
+/* texture slots — renderer.py:61-94 (albedo, topography, ocean, clouds, bathymetry, emissive, stars) */
+enum {
+    DE_TEX_ALBEDO = 0,     /* rgb8  (reference: rgba8, alpha unused)  renderer.py:61,171 */
+    DE_TEX_TOPOGRAPHY = 1, /* r8    renderer.py:66,177 */
+    DE_TEX_OCEAN = 2,      /* r8    renderer.py:71,183 */
+    DE_TEX_CLOUDS = 3,     /* r8    renderer.py:76,189 */
+    DE_TEX_BATHYMETRY = 4, /* r8    renderer.py:81,195 */
+    DE_TEX_EMISSIVE = 5,   /* r8    renderer.py:86,201 */
+    DE_TEX_STARS = 6,      /* rgb8  renderer.py:91,207 */
+    DE_TEX_COUNT = 7
+};
+
+/* de_params.flags */
+enum {
+    DE_FLAG_FIXED_WAVELENGTH = 1u << 0, /* BASELINE cfg1: skip spectrum_sample's draw, use fixed_wavelength */
+    DE_FLAG_CLAMP_SAMPLER = 1u << 1,    /* CLAMP_TO_EDGE instead of REPEAT texture addressing */
+    DE_FLAG_RAY_MARCHER = 1u << 2       /* integrate with ray_marcher (pathtracer.py:544-685) instead of path_tracer */
+};
+
+/* Scalar state of the reference Renderer (renderer.py:18-58), set through its set_* kernels (:224-266). */
+typedef struct de_params {
+    float camera_pos[3];      /* set_camera_pos  renderer.py:225 */
+    float look_at[3];         /* set_look_at     renderer.py:233 */
+    float up[3];              /* set_up (caller passes it normalised, as the kernel stores it) renderer.py:229 */
+    float fov;                /* half-angle used as tangent-plane half extent  renderer.py:237,271-275 */
+    float aspect_scale;       /* renderer.py:241 */
+    float sun_angle;          /* renderer.py:261 */
+    float sun_path_rot;       /* renderer.py:265 */
+    float land_height_scale;  /* renderer.py:58 */
+    float exposure;           /* renderer.py:245 */
+    float gamma;              /* renderer.py:249 */
+    int32_t selected_crf;     /* renderer.py:253 */
+    float vignette_strength;  /* renderer.py:20 */
+    float vignette_radius;    /* renderer.py:21 */
+    float vignette_center[2]; /* renderer.py:22 */
+    uint32_t flags;           /* DE_FLAG_* */
+    float fixed_wavelength;   /* nm, with DE_FLAG_FIXED_WAVELENGTH */
+    int32_t topo_res_override; /* land_normal's TOPOGRAPHY_TEX_RES[0] (pathtracer.py:20); 0 = width of the uploaded map */
+    int32_t reserved[7];
+} de_params;
+
+/* work counters of the last de_accumulate calls since de_reset (algorithmic bytes per sample) */
+typedef struct de_counters {
+    uint64_t samples;          /* paths traced */
+    uint64_t taps_r8;          /* bilinear taps of single-channel maps (4 texels = 4 B each) */
+    uint64_t taps_rgb8;        /* bilinear taps of colour maps (4 texels, 16 B each as rgba8 in the reference) */
+    uint64_t sphere_steps;     /* intersect_land iterations (pathtracer.py:37-44) */
+    uint64_t tracking_steps;   /* delta + ratio tracking iterations (pathtracer.py:91-112,130-141) */
+    uint64_t vertices;         /* path vertices (pathtracer.py:349) */
+    uint64_t rng_draws;
+    uint64_t reserved[9];
+} de_counters;
+
+typedef struct de_ctx de_ctx;
+
+/* Renderer.__init__ (renderer.py:17-58): allocate color_buffer / _rendered_image for a W x H image on HIP
+ * device `device`.  W must be a multiple of 16 and H of 8 (renderer.py:46). */
+int de_create(int device, int width, int height, de_ctx** out);
+int de_destroy(de_ctx* ctx);
+
+/* imread + from_numpy + copy_*_texture (renderer.py:61-94,171-210).  texels: row-major, row j = 0 is v = 0
+ * (south pole; Taichi imread is [x][y] with y up), `channels` bytes per texel (1 or 3). */
+int de_upload_texture(de_ctx* ctx, int slot, const uint8_t* texels, int width, int height, int channels);
+/* Synthetic stand-in for the NASA maps that the reference does not ship: generated on the GPU,
+ * deterministic in (slot, width, height, seed, variant).  variant 1 = cloud-heavy (BASELINE cfg4). */
+int de_generate_texture(de_ctx* ctx, int slot, int width, int height, uint32_t seed, int variant);
+/* Read a map back as uploaded (row-major, `channels` bytes per texel) — lets tests hand the same texels to the oracle. */
+int de_download_texture(de_ctx* ctx, int slot, uint8_t* out, uint64_t out_bytes);
+int de_texture_info(de_ctx* ctx, int slot, int* width, int* height, int* channels);
+
+/* LUT loading + copy_CIE_LUT_texture / copy_CRF_LUT_texture (renderer.py:96-134,147-167,212-222).
+ * cie: CIE.dat as read, f32[(x + y*441)*3 + c]; quantised to f16 inside, like the rgba16f texture.
+ * srgb2spec_f16: srgb2spec.dat as read, 300x3 binary16.  o3: ozone_cross_section.dat, f32[441].
+ * crf: (1024, n_crf, 3) f32 as returned by Renderer.load_crfs(). */
+int de_upload_luts(de_ctx* ctx, const float* cie, const uint16_t* srgb2spec_f16, const float* o3,
+                   const float* crf, int n_crf);
+
+int de_set_params(de_ctx* ctx, const de_params* p);
+int de_get_params(de_ctx* ctx, de_params* p);
+
+/* reset_framebuffer (renderer.py:367-369) */
+int de_reset(de_ctx* ctx);
+
+/* accumulate (renderer.py:371-380) `spp` times: adds samples current_spp .. current_spp+spp-1 of every pixel
+ * owned by (tile_rank, tile_world) to color_buffer, then current_spp += spp.  The RNG stream of a sample is a
+ * function of (seed, absolute pixel index, sample index) only, so images do not depend on tile_world.
+ * Ownership: 8x8-pixel tile (tx, ty) belongs to rank (tx + ty) % tile_world.  Asynchronous on the context stream. */
+int de_accumulate(de_ctx* ctx, int spp, uint64_t seed, int tile_rank, int tile_world);
+
+/* fetch_image (renderer.py:382-384, 346-365): runs _render_to_image with samples = current_spp and copies
+ * the (W, H, 3) f32 image to `out` (index (u*H + v)*3 + c, like the reference field). */
+int de_fetch_image(de_ctx* ctx, float* out);
+/* Same transform, result left on the device (pointer valid until the context is destroyed). */
+int de_render_to_image(de_ctx* ctx, const float** device_image);
+/* color_buffer as (W, H, 3) f32 — the raw HDR accumulation (renderer.py:25,330) */
+int de_fetch_hdr(de_ctx* ctx, float* out);
+/* Load an accumulation state: (W, H, 3) f32 HDR sums and the sample count they hold (resume of a progressive
+ * render; the reference keeps this state only in memory, renderer.py:23,25). */
+int de_upload_hdr(de_ctx* ctx, const float* hdr, int spp);
+int de_current_spp(de_ctx* ctx, int* spp);
+int de_set_current_spp(de_ctx* ctx, int spp);
+
+/* Multi-GPU plumbing (no reference counterpart): the HDR buffer's device address and element count
+ * (row-major [H][W][3] f32), so that the host can wrap it as a tensor and sum it across ranks with RCCL, and the
+ * stream the context launches on.  de_set_stream makes the context use an existing hipStream_t (e.g. torch's). */
+int de_hdr_device_ptr(de_ctx* ctx, void** ptr, uint64_t* n_floats);
+int de_set_stream(de_ctx* ctx, void* hip_stream);
+int de_synchronize(de_ctx* ctx);
+
+/* Timing of the last de_accumulate on the context's own stream, measured with HIP events (ms). */
+int de_last_accumulate_ms(de_ctx* ctx, float* ms);
+int de_get_counters(de_ctx* ctx, de_counters* out);
+int de_enable_counters(de_ctx* ctx, int enable);
+
+/* Debug / test hooks.
+ * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
+ * [H][W]) writes 4 floats: radiance, wavelength, number of RNG draws, number of path vertices.
+ * de_debug_math: evaluate a deterministic f32 elementary function on the GPU (fn: 0 exp, 1 log, 2 sin, 3 cos,
+ * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt), for bit-exact comparison against the oracle. */
+int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
+int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
+
+const char* de_last_error(void);
+int de_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIGITAL_EARTH_H */
