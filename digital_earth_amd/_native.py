@@ -57,6 +57,7 @@ SYMBOLS = {
     "de_current_spp": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     "de_set_current_spp": (ctypes.c_int, [_P, ctypes.c_int]),
     "de_hdr_device_ptr": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
+    "de_bind_hdr": (ctypes.c_int, [_P, _P, ctypes.c_uint64]),
     "de_set_stream": (ctypes.c_int, [_P, _P]),
     "de_synchronize": (ctypes.c_int, [_P]),
     "de_last_accumulate_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),

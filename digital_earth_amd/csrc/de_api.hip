@@ -105,7 +105,8 @@ struct de_ctx {
     FrameConsts* d_fc = nullptr;
     LambdaNode* d_nodes = nullptr;
     float* d_node_val = nullptr;
-    float* d_hdr = nullptr;      // [H][W][3]
+    float* d_hdr = nullptr;      // [H][W][3] (own allocation or bound by de_bind_hdr)
+    float* d_hdr_own = nullptr;
     float* d_image = nullptr;    // (W, H, 3)
     float* d_scratch = nullptr;  // (W, H, 3) / debug [H][W][4]
     uint32_t* d_tiles = nullptr;
@@ -250,7 +251,8 @@ int de_create(int device, int width, int height, de_ctx** out) {
     c->own_stream = (e == hipSuccess);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc(&c->d_hdr, npx * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_hdr_own, npx * 3 * sizeof(float));
+    c->d_hdr = c->d_hdr_own;
     if (e == hipSuccess) e = hipMalloc(&c->d_image, npx * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_scratch, npx * 4 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_fc, sizeof(FrameConsts));
@@ -276,7 +278,7 @@ int de_destroy(de_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr, c->d_image, c->d_scratch, c->d_tiles, c->d_counters};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -452,6 +454,15 @@ int de_hdr_device_ptr(de_ctx* c, void** ptr, uint64_t* n_floats) {
     if (!c || !ptr) return fail(DE_ERR_INVALID, "null argument");
     *ptr = c->d_hdr;
     if (n_floats) *n_floats = (uint64_t)c->W * c->H * 3;
+    return DE_OK;
+}
+int de_bind_hdr(de_ctx* c, void* device_ptr, uint64_t n_floats) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!device_ptr) { c->d_hdr = c->d_hdr_own; return DE_OK; }
+    if (n_floats < (uint64_t)c->W * c->H * 3) return fail(DE_ERR_INVALID, "bound HDR buffer is smaller than W*H*3 floats");
+    c->d_hdr = (float*)device_ptr;
     return DE_OK;
 }
 int de_set_stream(de_ctx* c, void* hip_stream) {

@@ -1,0 +1,65 @@
+"""Multi-GPU tile partition of one frame (no reference counterpart; BASELINE.json north_star).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The image grid is cut into 8x8-pixel
+tiles (one wavefront each); tile (tx, ty) belongs to rank (tx + ty) % world — a diagonal interleave, so that every
+rank gets the same mix of black sky, limb and cloudy day side.  Each rank accumulates its tiles into a full-size,
+zero-initialised HDR buffer; one sum-reduce of that buffer to rank 0 per fetch assembles the frame (the tiles are
+disjoint, so every pixel is x + 0 + ... + 0: exact).  The RNG stream of a sample depends only on
+(seed, absolute pixel, sample index), so the assembled frame is bit-identical to a 1-GPU render.
+
+The functions take torch tensors on any device, which is how the world_size-2 gloo tests exercise them on CPU.
+"""
+import numpy as np
+
+TILE = 8
+
+
+def tile_owner(tx, ty, world):
+    return (tx + ty) % world
+
+
+def owned_pixel_mask(width, height, rank, world):
+    """Boolean (W, H) mask of the pixels rank `rank` renders — the host-side statement of the kernel's ownership rule."""
+    tx = np.arange(width) // TILE
+    ty = np.arange(height) // TILE
+    return ((tx[:, None] + ty[None, :]) % world) == rank
+
+
+def tiles_per_rank(width, height, world):
+    tx, ty = width // TILE, height // TILE
+    owner = (np.arange(tx)[:, None] + np.arange(ty)[None, :]) % world
+    return np.bincount(owner.ravel(), minlength=world)
+
+
+def reduce_hdr(hdr, dst=0, group=None):
+    """Sum the per-rank HDR buffers onto rank `dst` (in place).  One collective per fetch, not per sample:
+    24.9 MB at 1080p, 99.5 MB at 4K."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(hdr, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return hdr
+
+
+class DistributedFrame:
+    """Binds a Renderer to this process's rank: torch owns the HDR buffer (so RCCL can reduce it in place) and the
+    renderer launches on torch's current stream (so the collective is ordered after the render kernel)."""
+
+    def __init__(self, renderer, rank, world, device_index):
+        import torch
+        self.torch = torch
+        self.r = renderer
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", device_index)
+        W, H = renderer.image_res
+        self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
+        renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
+        renderer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        renderer.set_tile_partition(rank, world)
+
+    def render_frame(self, spp):
+        """reset -> accumulate(spp) on this rank's tiles -> reduce to rank 0 -> display transform on rank 0 (device)."""
+        self.r.reset_framebuffer()            # zeroes the bound HDR buffer on the shared stream
+        self.r.accumulate(spp)
+        reduce_hdr(self.hdr, dst=0)
+        if self.rank == 0:
+            self.r.render_to_image_device()

@@ -353,6 +353,18 @@ class Renderer:
         check(self._lib.de_hdr_device_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
+    def bind_hdr(self, device_ptr, n_floats):
+        """Accumulate into caller-owned device memory (e.g. a torch tensor) instead of the library's buffer."""
+        check(self._lib.de_bind_hdr(self._h, ctypes.c_void_p(device_ptr), int(n_floats)))
+
+    def render_to_image_device(self):
+        """Run the display transform and leave the (W, H, 3) image on the device; returns its address."""
+        if not self._textures_copied:
+            self.copy_textures()
+        p = ctypes.c_void_p()
+        check(self._lib.de_render_to_image(self._h, ctypes.byref(p)))
+        return p.value
+
     def set_stream(self, hip_stream_handle):
         check(self._lib.de_set_stream(self._h, ctypes.c_void_p(hip_stream_handle)))
 

@@ -137,6 +137,9 @@ int de_set_current_spp(de_ctx* ctx, int spp);
  * (row-major [H][W][3] f32), so that the host can wrap it as a tensor and sum it across ranks with RCCL, and the
  * stream the context launches on.  de_set_stream makes the context use an existing hipStream_t (e.g. torch's). */
 int de_hdr_device_ptr(de_ctx* ctx, void** ptr, uint64_t* n_floats);
+/* Use caller-owned device memory (n_floats >= W*H*3, e.g. a torch tensor's data_ptr) as the HDR buffer; the current
+ * contents are kept as the accumulation state.  ptr = NULL returns to the library's own buffer. */
+int de_bind_hdr(de_ctx* ctx, void* device_ptr, uint64_t n_floats);
 int de_set_stream(de_ctx* ctx, void* hip_stream);
 int de_synchronize(de_ctx* ctx);
 
