@@ -1,0 +1,51 @@
+"""Host-side logic that needs no GPU: camera math, config round trip, tile partition."""
+import numpy as np
+
+from digital_earth_amd import parallel
+from digital_earth_amd.earth_viewer import Camera, Config, load_config, np_rotate_matrix, np_normalize
+
+
+def test_rotate_matrix_is_a_rotation():
+    m = np_rotate_matrix(np.array([0.0, 1.0, 0.0]), 0.3)[:3, :3]
+    assert np.allclose(m @ m.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(m) - 1) < 1e-12
+    v = m @ np.array([1.0, 0, 0])
+    assert np.allclose(v, [np.cos(0.3), 0, -np.sin(0.3)])   # counter-clockwise about +y (lib/math_utils.py:83-102)
+
+
+def test_camera_defaults_and_motion():
+    c = Camera(None, (0, 1, 0))
+    assert (c.position == [-15000000., 0.0, 15000000.]).all() and (c.look_at == 0).all()   # earth_viewer.py:26-27
+    assert np.allclose(c.target_dir, np_normalize(np.array([1.0, 0, -1.0])))
+    d0 = np.linalg.norm(c.look_at - c.position)
+    c.rotate(0.01, 0.0)
+    assert abs(np.linalg.norm(c.look_at - c.position) - d0) < 1e-3     # rotation keeps the view distance
+    p0 = c.position.copy()
+    c.move(c.target_dir, 0.1)
+    assert np.linalg.norm(c.position - p0) > 0
+    assert c.update_camera(0.1) is False
+
+
+def test_config_round_trip(tmp_path):
+    a = load_config("config - Apollo 11.txt")
+    p = tmp_path / "config.txt"
+    a.write(str(p))
+    b = load_config(str(p))
+    for k in ("fov", "aspect_scale", "exposure", "selected_crf", "gamma", "sun_angle", "sun_path_rot"):
+        assert getattr(a, k) == getattr(b, k)
+    assert (a.position == b.position).all() and (a.look_at == b.look_at).all() and (a.up == b.up).all()
+    assert len(open(p).read().splitlines()) == 10
+
+
+def test_tile_partition_masks():
+    W, H = 1920, 1080
+    for world in (1, 2, 4, 8):
+        masks = [parallel.owned_pixel_mask(W, H, r, world) for r in range(world)]
+        total = np.sum(masks, axis=0)
+        assert (total == 1).all()                                      # every pixel has exactly one owner
+        counts = parallel.tiles_per_rank(W, H, world)
+        assert counts.sum() == (W // 8) * (H // 8) and counts.max() - counts.min() <= 135   # balanced to within one tile column
+        for r in range(world):
+            assert masks[r].sum() == counts[r] * 64
+    # ownership rule used by the kernel: 8x8 tile (tx, ty) -> (tx + ty) % world
+    m = parallel.owned_pixel_mask(64, 32, 1, 4)
+    assert m[8, 0] and not m[0, 0] and m[0, 8] and m[7 + 8 * 5, 7]
