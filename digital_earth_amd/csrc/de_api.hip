@@ -4,12 +4,14 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
 
 // single translation unit: the kernels are compiled together with the host API
 #include "render_kernel.hip"
+#include "render_kernel_v2.hip"
 #include "aux_kernels.hip"
 
 namespace {
@@ -115,6 +117,7 @@ struct de_ctx {
     bool count = false;
     de_counters counters;
     int current_spp = 0;
+    int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip)
 };
 
 namespace {
@@ -216,6 +219,11 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
+    if (!march && c->kernel_variant == 2) {
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), grid, block, 0, c->stream, a);
+        return;
+    }
     if (!clamp && !march) hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
     else if (clamp && !march) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
     else if (!clamp && march) hipLaunchKernelGGL((render_kernel<false, true, MODE>), grid, block, 0, c->stream, a);
@@ -245,6 +253,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     de_ctx* c = new de_ctx();
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
+    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] == '1') c->kernel_variant = 1; }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -486,6 +495,11 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DE_OK;
+}
+int de_set_kernel_variant(de_ctx* c, int variant) {
+    if (!c || (variant != 1 && variant != 2)) return fail(DE_ERR_INVALID, "kernel variant must be 1 or 2");
+    c->kernel_variant = variant;
     return DE_OK;
 }
 int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }

@@ -1,0 +1,526 @@
+// render_kernel_v2.hip — path_tracer (pathtracer.py:316-469) as a WAVEFRONT-LEVEL STATE MACHINE.
+//
+// Why: in the straightforward kernel (render_kernel.hip) every lane walks the reference's nested loops
+// (250-step sphere trace, two delta-tracking loops, two ratio-tracking loops per light sample, 25 vertices) and the
+// 64 lanes of a wave serialise on each other's trip counts: rocprofv3 measured 11.5 % VALU lane utilisation
+// (profiles/r1a_summary.md).  Here each lane carries an explicit `state`; every trip of the wave loop advances
+// EVERY lane that is inside one of the hot loops by one iteration, whatever loop of whatever path vertex it is in:
+//
+//   TAP class   one evaluation point that needs |p|, p/|p|, the sphere UV map and one bilinear map tap
+//               — a sphere-trace step (topography), a cloud-shell tracking step (cloud map), a normal tap
+//   GAS class   one tracking step through the Rayleigh/Mie/ozone profiles
+//
+// Everything between loops (segment set-up, event resolution, shading, sample start/end) is "transition" code: it
+// runs when enough lanes are waiting for it (or nothing else can run), in pipeline order, so a lane falls through
+// consecutive transitions in one pass.  Lanes start their next sample immediately when a path ends (path
+// regeneration), so short paths do not idle the lane.
+//
+// Results are IDENTICAL to render_kernel.hip and to the CPU oracle: each lane executes the same arithmetic in the
+// same order on its own RNG stream; only the interleaving between lanes changes.
+#include "de_kernels.h"
+
+namespace v2 {
+
+enum { EV_NULL = 0, EV_ABSORB = 1, EV_SCATTER = 2 };
+
+// lane states.  Loop states first (class tests are range tests).
+enum : int {
+    // --- TAP class
+    S_ST_P = 0,      // sphere trace, path ray                       pathtracer.py:37-44
+    S_ST_S,          // sphere trace, shadow ray from the surface    pathtracer.py:422
+    S_NRM0, S_NRM1, S_NRM2, S_NRM3,   // land_normal's four SDF evaluations   pathtracer.py:16-25
+    S_DT_C,          // delta tracking, cloud shell                  pathtracer.py:198
+    S_RT_C_V,        // ratio tracking, cloud shell, light sample of a volume vertex   pathtracer.py:231
+    S_RT_C_S,        // same for a surface vertex
+    // --- GAS class
+    S_DT_G,          // delta tracking, gases                        pathtracer.py:186
+    S_RT_G_V,        // ratio tracking, gases (volume vertex)        pathtracer.py:227
+    S_RT_G_S,        // ratio tracking, gases (surface vertex)
+    // --- transitions, in pipeline order
+    S_AFTER_ST_P, S_AFTER_ST_S,
+    S_CLOUD_SETUP_DT, S_CLOUD_SETUP_V, S_CLOUD_SETUP_S,
+    S_AFTER_DT_C,
+    S_SC_FINISH,
+    S_SURF_SETUP,
+    S_SURF_FINISH,
+    S_END, S_END_MISS,
+    S_NEW,
+    S_VERTEX,
+    S_DONE
+};
+DE_DEV bool is_tap(int s) { return s <= S_RT_C_S; }
+DE_DEV bool is_gas(int s) { return s >= S_DT_G && s <= S_RT_G_S; }
+DE_DEV bool is_cloud_tap(int s) { return s >= S_DT_C && s <= S_RT_C_S; }
+
+struct Work2 { uint32_t taps_r8, taps_rgb, sphere_steps, tracking_steps, vertices, draws; };
+
+// pathtracer.py:145-169
+DE_DEV void intersect_cloud_limits(vec3 ray_pos, vec3 ray_dir, float land_isection, float* t_start_out, float* t_max_out) {
+    float t_start = 0.0f, t_max = 0.0f;
+    float elevation = length(ray_pos);
+    vec2_ lower = rsi(ray_pos, ray_dir, DE_CLOUDS_LOWER);
+    vec2_ upper = rsi(ray_pos, ray_dir, DE_CLOUDS_UPPER);
+    if (elevation >= DE_CLOUDS_UPPER) {
+        t_start = de_max(0.0f, upper.x);
+        t_max = (lower.y >= 0.0f) ? lower.x : upper.y;
+        if (upper.y < 0.0f) t_max = -1.0f;
+    } else if (elevation >= DE_CLOUDS_LOWER) {
+        t_start = 0.0f;
+        t_max = (lower.y >= 0.0f) ? lower.x : upper.y;
+    } else {
+        t_start = lower.y;
+        t_max = upper.y;
+        if (land_isection > 0.0f) t_max = -1.0f;
+    }
+    *t_start_out = t_start; *t_max_out = t_max;
+}
+// pathtracer.py:235-247
+DE_DEV float evaluate_phase(const FrameConsts& fc, vec3 ray_dir, vec3 light_dir, int id, bool reduce_peak) {
+    float phase = 0.0f;
+    float c = dot(ray_dir, light_dir);
+    if (id == RAYLEIGH_ID) phase += rayleigh_phase(c);
+    else if (id == MIE_ID) phase += klein_nishina_phase(c, DE_MIE_ASYMMETRY, fc.kn_log);
+    else if (id == CLOUD_ID) phase += cloud_phase(fc.cloud, c, reduce_peak);
+    else if (id == ISOTROPIC_CLOUD_ID) phase += (float)(1.0 / (4.0 * M_PI));
+    return phase;
+}
+// pathtracer.py:249-261
+DE_DEV vec3 sample_phase(const FrameConsts& fc, Rng& rng, vec3 ray_dir, int id, bool reduce_peak, float* phase_div_pdf) {
+    *phase_div_pdf = 1.0f;
+    if (id == RAYLEIGH_ID || id == ISOTROPIC_CLOUD_ID) {
+        float r0 = rng_next(rng);
+        float r1 = rng_next(rng);
+        vec3 d = sample_sphere(r0, r1);
+        *phase_div_pdf = evaluate_phase(fc, ray_dir, d, id, reduce_peak) * (float)(4.0 * M_PI);
+        return d;
+    } else if (id == MIE_ID) {
+        return sample_klein_nishina_phase(rng, ray_dir, DE_MIE_ASYMMETRY);
+    }
+    return sample_cloud_phase(fc.cloud, rng, ray_dir, reduce_peak);
+}
+DE_DEV float srgb_to_spectrum(const LambdaNode& L, vec3 rgb) {
+    return (L.s2s_valid != 0.0f) ? dot(rgb, v3(L.c0, L.c1, L.c2)) : 0.0f;
+}
+DE_DEV int spectrum_node(const float* node_val, float sample) {   // lib/colour.py:21-39
+    int n = 1;
+    for (int it = 0; it < 8; ++it) {
+        float val = node_val[n];
+        if (val < sample) n = 2 * n + 1;
+        else if (val > sample) n = 2 * n;
+        else break;
+    }
+    return n;
+}
+DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {   // renderer.py:269-279
+    float fov = fc.fov;
+    float fu = (2.0f * fov * ((float)u + rng_next(rng)) / (float)H - fov * fc.aspect_ratio - 1e-5f) * fc.aspect_scale;
+    float fv = 2.0f * fov * ((float)v + rng_next(rng)) / (float)H - fov - 1e-5f;
+    return normalized(fc.d + fu * fc.du + fv * fc.dv);
+}
+
+}  // namespace v2
+
+#ifndef DE_V2_PENDING_THRESHOLD
+#define DE_V2_PENDING_THRESHOLD 12   // run the transition pass when at least this many lanes wait for it
+#endif
+
+// MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
+template <bool CLAMP, int MODE>
+__global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
+    using namespace v2;
+    const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wave >= a.n_tiles) return;
+    const uint32_t tile = a.tiles[wave];
+    const int lane = threadIdx.x & 63;
+    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (lane & 7);
+    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (lane >> 3);
+    const uint32_t pixel = (uint32_t)(v * a.W + u);
+    const FrameConsts& fc = *a.fc;
+    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+
+    Work2 wk = {0, 0, 0, 0, 0, 0};
+    float* px = a.hdr + (size_t)pixel * 3;
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+    if (MODE != 2) { acc_r = px[0]; acc_g = px[1]; acc_b = px[2]; }
+
+    // ---- per-lane path state
+    Rng rng; rng.s0 = 1; rng.s1 = 0; rng.draws = 0;
+    int node = 0;
+    int s_done = 0;                       // samples finished
+    vec3 P = v3(0, 0, 0), D = v3(0, 0, 1), LD = v3(0, 0, 1), C = v3(0, 0, 0), N = v3(0, 0, 1);
+    float thr = 1.0f, Ls = 0.0f;
+    int sc = 0;
+    float t = 0.0f, tmax = 0.0f, trn = 1.0f, trg = 1.0f;
+    int cnt = 0;
+    float atm_x = 0.0f, atm_y = 0.0f;     // rsi(P, W, atmosphere) of the ray being traced
+    float isect = 0.0f, rmo_t = 0.0f;
+    int rmo_event = 0, ev_id = 0;         // ev_id: interaction id of the resolved event
+    float li = -1.0f;                     // land_isection argument of the light-sample transmittance
+    float d0 = 0.0f, alb = 0.0f, ocean = 0.0f, bathy = 0.0f;
+    float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f;
+    int state = S_NEW;
+    if (a.spp_count <= 0) state = S_DONE;
+
+    for (;;) {
+        const bool tapL = is_tap(state), gasL = is_gas(state);
+        const unsigned long long m_tap = __ballot(tapL), m_gas = __ballot(gasL);
+        const unsigned long long m_live = __ballot(state != S_DONE);
+        if (m_live == 0ull) break;
+
+        // ============================================================ TAP class
+        if (m_tap != 0ull) {
+            if (tapL) {
+                const bool cloud = is_cloud_tap(state);
+                const vec3 W = (state == S_ST_P || state == S_DT_C) ? D : LD;
+                bool alive = true;
+                vec3 Q;
+                float maxc = 0.0f, ext_w = 0.0f;
+                if (cloud) {
+                    ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
+                    maxc = ext_w * DE_CLOUDS_DENSITY;
+                    float t_step = -de_log(rng_next(rng)) / maxc;
+                    C = C + t_step * W;
+                    t += t_step;
+                    if (MODE) wk.tracking_steps++;
+                    alive = !(t >= tmax);
+                    Q = C;
+                } else if (state <= S_ST_S) {
+                    Q = P + W * t;
+                } else {
+                    const float e = fc.normal_eps;
+                    Q = P;
+                    if (state == S_NRM1) Q = P - v3(e, 0.0f, 0.0f);
+                    if (state == S_NRM2) Q = P - v3(0.0f, e, 0.0f);
+                    if (state == S_NRM3) Q = P - v3(0.0f, 0.0f, e);
+                }
+                if (alive) {
+                    const float len = length(Q);
+                    const bool do_tap = !cloud || (len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER);
+                    float tex = 0.0f;
+                    if (do_tap) {
+                        const vec3 n = Q / len;
+                        if (MODE) wk.taps_r8++;
+                        // per-lane map select (two maps only in this class)
+                        TexR8 T;
+                        T.data = cloud ? a.clouds.data : a.topo.data;
+                        T.w = cloud ? a.clouds.w : a.topo.w; T.h = cloud ? a.clouds.h : a.topo.h;
+                        T.tiles_x = cloud ? a.clouds.tiles_x : a.topo.tiles_x;
+                        T.wf = cloud ? a.clouds.wf : a.topo.wf; T.hf = cloud ? a.clouds.hf : a.topo.hf;
+                        tex = sphere_tap_r8<CLAMP>(T, n);
+                    }
+                    if (cloud) {
+                        // get_clouds_density, pathtracer.py:48-65
+                        float density = 0.0f;
+                        if (do_tap) {
+                            float h = (len - DE_CLOUDS_LOWER) / DE_CLOUDS_THICKNESS;
+                            const float split = 0.2f;
+                            density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
+                        }
+                        float es = ext_w * (density * DE_CLOUDS_DENSITY);
+                        if (state == S_DT_C) {
+                            float rand = rng_next(rng);
+                            if (rand < es / maxc) {
+                                rmo_event |= ((rng_next(rng) < 0.99f) ? EV_SCATTER : EV_ABSORB) << 4;   // cloud event in bits 4-5
+                                state = S_AFTER_DT_C;
+                            }
+                        } else {
+                            trn *= 1.0f - es / maxc;
+                            if (trn < 1e-5f) state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
+                        }
+                    } else {
+                        float sdf = len - DE_PLANET_R - fc.land_height_scale * tex;
+                        if (state <= S_ST_S) {
+                            t += sdf;
+                            cnt++;
+                            if (MODE) wk.sphere_steps++;
+                            if (t > MAX_RAY_DIST || de_abs(sdf) < t * 0.0001f || cnt >= 250) state = (state == S_ST_P) ? S_AFTER_ST_P : S_AFTER_ST_S;
+                        } else {
+                            if (state == S_NRM0) d0 = sdf;
+                            else if (state == S_NRM1) N.x = d0 - sdf;
+                            else if (state == S_NRM2) N.y = d0 - sdf;
+                            else N.z = d0 - sdf;
+                            state = (state == S_NRM3) ? S_SURF_SETUP : state + 1;
+                        }
+                    }
+                } else {
+                    // t >= t_max: the tracking loop ends without an event
+                    if (state == S_DT_C) state = S_AFTER_DT_C;
+                    else state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
+                }
+            }
+        }
+
+        // ============================================================ GAS class
+        if (m_gas != 0ull) {
+            if (gasL) {
+                const vec3 W = (state == S_DT_G) ? D : LD;
+                float t_step = -de_log(rng_next(rng)) / maxr;
+                C = C + t_step * W;
+                t += t_step;
+                if (MODE) wk.tracking_steps++;
+                if (t >= tmax) {
+                    if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
+                    else { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                } else {
+                    vec3 dens = get_density(de_sqrt((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
+                    vec3 es = v3(ext_r, ext_m, ext_o) * dens;
+                    float sum = (es.x + es.y) + es.z;
+                    if (state == S_DT_G) {
+                        float rand = rng_next(rng);
+                        if (rand < sum / maxr) {
+                            int id = 0;
+                            float cmf = es.x;
+                            if (!(rand < cmf / maxr)) {
+                                id = 1;
+                                cmf += es.y;
+                                if (!(rand < cmf / maxr)) {
+                                    id = 2;
+                                    cmf += es.z;
+                                    if (!(rand < cmf / maxr)) id = 3;
+                                }
+                            }
+                            const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));
+                            rmo_event = (rng_next(rng) < albedo) ? EV_SCATTER : EV_ABSORB;
+                            rmo_t = t;
+                            ev_id = id;
+                            state = S_CLOUD_SETUP_DT;
+                        }
+                    } else {
+                        trn *= 1.0f - sum / maxr;
+                        if (trn < 1e-5f) { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                    }
+                }
+            }
+        }
+
+        // ============================================================ transitions
+        const unsigned long long m_pend = __ballot(state >= S_AFTER_ST_P && state != S_DONE);
+        const int n_pend = __popcll(m_pend);
+        const unsigned long long m_loop = __ballot(is_tap(state) || is_gas(state));
+        if (n_pend == 0 || (n_pend < DE_V2_PENDING_THRESHOLD && m_loop != 0ull)) continue;
+
+        // ---- after a sphere trace (pathtracer.py:46): result, then the gas segment of the same ray
+        if (__ballot(state == S_AFTER_ST_P || state == S_AFTER_ST_S) != 0ull) {
+            if (state == S_AFTER_ST_P || state == S_AFTER_ST_S) {
+                const float hit = (t < MAX_RAY_DIST) ? t : -1.0f;
+                float land_isection;
+                if (state == S_AFTER_ST_P) { isect = hit; land_isection = hit; }
+                else { li = (hit < 0.0f) ? -1.0f : 0.0f; land_isection = li; }
+                // sample_interaction / sample_transmittance head (pathtracer.py:180-184, 219-225); rsi(atmosphere) is the
+                // value intersect_land already computed for this ray
+                float t_start = de_max(0.0f, atm_x);
+                float t_max = (land_isection >= 0.0f) ? land_isection : atm_y;
+                if (atm_y < 0.0f) t_max = -1.0f;
+                const vec3 W = (state == S_AFTER_ST_P) ? D : LD;
+                t = t_start; tmax = t_max;
+                C = P + t * W;
+                trn = 1.0f;
+                if (t_start < t_max) state = (state == S_AFTER_ST_P) ? S_DT_G : S_RT_G_S;
+                else if (state == S_AFTER_ST_P) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
+                else { trg = 1.0f; state = S_CLOUD_SETUP_S; }
+            }
+        }
+        // ---- cloud-shell segment (pathtracer.py:189,195-198 / 229-231)
+        if (__ballot(state >= S_CLOUD_SETUP_DT && state <= S_CLOUD_SETUP_S) != 0ull) {
+            if (state >= S_CLOUD_SETUP_DT && state <= S_CLOUD_SETUP_S) {
+                const bool dt = (state == S_CLOUD_SETUP_DT);
+                const vec3 W = dt ? D : LD;
+                float t_start, t_max;
+                intersect_cloud_limits(P, W, dt ? isect : li, &t_start, &t_max);
+                bool run = true;
+                if (dt) run = (rmo_event == EV_NULL) || (rmo_t > t_start);
+                t = t_start; tmax = t_max;
+                C = P + t * W;
+                trn = 1.0f;
+                const bool enter = run && (t_start < t_max);
+                if (dt) state = enter ? S_DT_C : S_AFTER_DT_C;
+                else if (state == S_CLOUD_SETUP_V) state = enter ? S_RT_C_V : S_SC_FINISH;
+                else state = enter ? S_RT_C_S : S_SURF_FINISH;
+            }
+        }
+        // ---- event resolution, light sample, branch (pathtracer.py:200-205, 369-375, 404, 441-444)
+        if (__ballot(state == S_AFTER_DT_C) != 0ull) {
+            if (state == S_AFTER_DT_C) {
+                const int cloud_event = rmo_event >> 4;
+                const int gas_event = rmo_event & 15;
+                int event = gas_event;
+                float tt = rmo_t;
+                int id = ev_id;
+                // cloud_t is the current t when the cloud loop produced an event
+                if (cloud_event > 0 && (t < rmo_t || gas_event == EV_NULL)) { tt = t; id = CLOUD_ID; event = cloud_event; }
+                if (sc > 9 && id == CLOUD_ID) id = ISOTROPIC_CLOUD_ID;
+                ev_id = id;
+                LD = tangent_space_apply(fc.light_dir, sample_cone(rng, fc.sun_cos_angle));
+                if (event == EV_ABSORB) {
+                    state = S_END;
+                } else if (event == EV_SCATTER) {
+                    P = P + tt * D;
+                    const bool blocked = rsi(P, LD, DE_PLANET_R).y > 0.0f;
+                    if (blocked) {
+                        trg = 0.0f; trn = 1.0f;           // direct_transmittance stays 0
+                        li = 1.0f;                        // marks "blocked" for S_SC_FINISH
+                        state = S_SC_FINISH;
+                    } else {
+                        li = -1.0f;
+                        vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
+                        float t_start = de_max(0.0f, atmos.x);
+                        float t_max = atmos.y;            // land_isection = -1
+                        if (atmos.y < 0.0f) t_max = -1.0f;
+                        t = t_start; tmax = t_max;
+                        C = P + t * LD;
+                        trn = 1.0f;
+                        if (t_start < t_max) state = S_RT_G_V;
+                        else { trg = 1.0f; state = S_CLOUD_SETUP_V; }
+                    }
+                } else if (isect > 0.0f) {
+                    P = P + D * isect;                    // land_pos
+                    state = S_NRM0;
+                } else {
+                    state = (sc == 0) ? S_END_MISS : S_END;
+                }
+            }
+        }
+        // ---- volume vertex: in-scattering, phase sampling, roulette (pathtracer.py:394-401, 448-453)
+        if (__ballot(state == S_SC_FINISH) != 0ull) {
+            if (state == S_SC_FINISH) {
+                const LambdaNode& L = a.nodes[node];
+                const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
+                const float direct_phase = evaluate_phase(fc, D, LD, ev_id, sc > 0);
+                Ls += thr * direct_tr * L.sun_irradiance * direct_phase;
+                float phase_div_pdf;
+                vec3 nd = sample_phase(fc, rng, D, ev_id, sc > 0, &phase_div_pdf);
+                D = nd;
+                thr *= phase_div_pdf;
+                state = S_VERTEX;
+                if (sc > 3) {
+                    float termination_p = de_max(0.05f, 1.0f - thr);
+                    if (rng_next(rng) < termination_p) state = S_END;
+                    else thr /= 1.0f - termination_p;
+                }
+                sc++;
+                if (state == S_VERTEX && sc >= 25) state = S_END;
+            }
+        }
+        // ---- surface vertex, first half: normal, material, emissive, shadow-ray set-up (pathtracer.py:406-422)
+        if (__ballot(state == S_SURF_SETUP) != 0ull) {
+            if (state == S_SURF_SETUP) {
+                const LambdaNode& L = a.nodes[node];
+                N = normalized(N);
+                vec3 n = normalized(P);
+                vec2_ uv = sphere_UV_map(n);
+                float uu = fract_(uv.x * 1.0f), vv = fract_(uv.y * 1.0f);
+                ocean = tap_r8<CLAMP>(a.ocean, uu, vv);
+                vec3 tex = tap_rgb<CLAMP>(a.albedo, uu, vv);
+                vec3 land = mix3(lum3(tex), tex, 6.5f);
+                float greenery = sqr(land.y / lum(land));
+                greenery = smoothstep_(1.5f, 1.9f, greenery);
+                land = (1.0f * tex) / (greenery * 0.7f + 1.0f);
+                land = mix3(lum3(land), land, 1.4f - greenery * 0.45f);
+                land = mix3(land, (land * v3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));
+                vec3 ocean_albedo = mix3(lum3(tex), tex, 0.75f) * 0.9f;
+                vec3 albedo_srgb = mix3(land, ocean_albedo, ocean);
+                bathy = tap_r8<CLAMP>(a.bathy, uu, vv);
+                float emissive = tap_r8<CLAMP>(a.emissive, uu, vv);
+                if (MODE) { wk.taps_r8 += 3; wk.taps_rgb += 1; }
+                alb = srgb_to_spectrum(L, albedo_srgb);
+                Ls += thr * emissive * L.night_power;
+                P = P * fc.offset_scale;                                 // offset_pos
+                // intersect_land(offset_pos, light_dir) head
+                vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
+                atm_x = atmos.x; atm_y = atmos.y;
+                t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
+                cnt = 0;
+                state = S_ST_S;
+            }
+        }
+        // ---- surface vertex, second half: direct light, bounce, roulette (pathtracer.py:431-439, 448-453)
+        if (__ballot(state == S_SURF_FINISH) != 0ull) {
+            if (state == S_SURF_FINISH) {
+                const LambdaNode& L = a.nodes[node];
+                const float direct_tr = trg * trn;
+                const bool visible = li < 0.0f;
+                float direct_ndl;
+                float direct_brdf = earth_brdf(alb, ocean, bathy, -D, N, LD, &direct_ndl);
+                Ls += thr * direct_tr * (visible ? 1.0f : 0.0f) * L.sun_irradiance * direct_brdf * direct_ndl;
+                vec3 view_dir = -D;
+                D = sample_hemisphere_cosine_weighted(rng, N);
+                float unused;
+                float brdf = earth_brdf(alb, ocean, bathy, view_dir, N, D, &unused);
+                thr *= brdf * (float)M_PI;
+                state = S_VERTEX;
+                if (sc > 3) {
+                    float termination_p = de_max(0.05f, 1.0f - thr);
+                    if (rng_next(rng) < termination_p) state = S_END;
+                    else thr /= 1.0f - termination_p;
+                }
+                sc++;
+                if (state == S_VERTEX && sc >= 25) state = S_END;
+            }
+        }
+        // ---- end of path: miss epilogue, NaN guard, colour accumulation (pathtracer.py:455-469, renderer.py:329-330)
+        if (__ballot(state == S_END || state == S_END_MISS) != 0ull) {
+            if (state == S_END || state == S_END_MISS) {
+                const LambdaNode& L = a.nodes[node];
+                if (state == S_END_MISS) {
+                    if (dot(fc.light_dir, D) > fc.sun_cos_angle) Ls += L.sun_power;     // D is still the primary direction
+                    if (MODE) wk.taps_rgb += 1;
+                    vec3 stars_srgb = sphere_tap_rgb<CLAMP>(a.stars, normalized(D));
+                    float stars_power = srgb_to_spectrum(L, stars_srgb);
+                    Ls += stars_power * L.sun_power * 0.0000001f;
+                }
+                if (__builtin_isinf(Ls) || Ls != Ls || Ls < 0.0f) Ls = 0.0f;
+                vec3 xyz = (Ls * v3(L.rx, L.ry, L.rz)) * L.rcp_pdf;
+                vec3 rgb = xyz_to_rgb_d65(xyz);
+                acc_r += rgb.x; acc_g += rgb.y; acc_b += rgb.z;
+                if (MODE) wk.draws += rng.draws;
+                if (MODE == 2) {
+                    float* q = a.debug_out + (size_t)pixel * 4;
+                    q[0] = Ls; q[1] = L.wavelength; q[2] = (float)rng.draws; q[3] = (float)wk.vertices;
+                }
+                s_done++;
+                state = S_NEW;
+            }
+        }
+        // ---- next sample of this pixel (renderer.py:305-314)
+        if (__ballot(state == S_NEW) != 0ull) {
+            if (state == S_NEW) {
+                if (s_done >= a.spp_count) {
+                    state = S_DONE;
+                } else {
+                    rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_done));
+                    node = 0;
+                    if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
+                    const LambdaNode& L = a.nodes[node];
+                    ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; maxr = L.max_ext_rmo;
+                    D = v2::get_cast_dir(rng, fc, a.H, u, v);
+                    P = fc.cam_pos;
+                    thr = 1.0f; Ls = 0.0f; sc = 0;
+                    state = S_VERTEX;
+                }
+            }
+        }
+        // ---- start of a vertex: intersect_land head (pathtracer.py:29-35)
+        if (__ballot(state == S_VERTEX) != 0ull) {
+            if (state == S_VERTEX) {
+                if (MODE) wk.vertices++;
+                vec2_ atmos = rsi(P, D, DE_ATMOS_UPPER);
+                atm_x = atmos.x; atm_y = atmos.y;
+                t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
+                cnt = 0;
+                rmo_event = 0;
+                state = S_ST_P;
+            }
+        }
+    }
+
+    if (MODE != 2) { px[0] = acc_r; px[1] = acc_g; px[2] = acc_b; }
+    if (MODE == 1) {
+        atomicAdd(&a.counters[0], (unsigned long long)a.spp_count);
+        atomicAdd(&a.counters[1], (unsigned long long)wk.taps_r8);
+        atomicAdd(&a.counters[2], (unsigned long long)wk.taps_rgb);
+        atomicAdd(&a.counters[3], (unsigned long long)wk.sphere_steps);
+        atomicAdd(&a.counters[4], (unsigned long long)wk.tracking_steps);
+        atomicAdd(&a.counters[5], (unsigned long long)wk.vertices);
+        atomicAdd(&a.counters[6], (unsigned long long)wk.draws);
+    }
+}

@@ -343,6 +343,10 @@ class Renderer:
     def enable_counters(self, on=True):
         check(self._lib.de_enable_counters(self._h, 1 if on else 0))
 
+    def set_kernel_variant(self, variant):
+        """2 = wave-level state machine (default), 1 = per-lane loops; identical results."""
+        check(self._lib.de_set_kernel_variant(self._h, int(variant)))
+
     def counters(self):
         c = DeCounters()
         check(self._lib.de_get_counters(self._h, ctypes.byref(c)))

@@ -147,6 +147,9 @@ int de_synchronize(de_ctx* ctx);
 int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);
+/* A/B hook: 2 (default) = wave-level state-machine kernel, 1 = per-lane loop kernel.  Same results, bit for bit.
+ * The ray marcher always runs on variant 1.  Environment DE_KERNEL=1 selects variant 1 at de_create. */
+int de_set_kernel_variant(de_ctx* ctx, int variant);
 
 /* Debug / test hooks.
  * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
