@@ -211,6 +211,10 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch;
+    a->pend_thr = 12; a->tune_a = 0; a->tune_b = 0;
+    if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
+    if (const char* e = getenv("DE_V2_A")) a->tune_a = atoi(e);
+    if (const char* e = getenv("DE_V2_B")) a->tune_b = atoi(e);
     return DE_OK;
 }
 

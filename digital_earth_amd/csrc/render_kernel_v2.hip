@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
         const unsigned long long m_pend = __ballot(state >= S_AFTER_ST_P && state != S_DONE);
         const int n_pend = __popcll(m_pend);
         const unsigned long long m_loop = __ballot(is_tap(state) || is_gas(state));
-        if (n_pend == 0 || (n_pend < DE_V2_PENDING_THRESHOLD && m_loop != 0ull)) continue;
+        if (n_pend == 0 || (n_pend < a.pend_thr && m_loop != 0ull)) continue;
 
         // ---- after a sphere trace (pathtracer.py:46): result, then the gas segment of the same ray
         if (__ballot(state == S_AFTER_ST_P || state == S_AFTER_ST_S) != 0ull) {
