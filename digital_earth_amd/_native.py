@@ -29,7 +29,9 @@ class DeCounters(ctypes.Structure):
                 ("rng_draws", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 9)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d["sched"] = [int(x) for x in self.reserved]
+        return d
 
 
 DE_FLAG_FIXED_WAVELENGTH = 1 << 0

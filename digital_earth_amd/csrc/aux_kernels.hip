@@ -170,6 +170,31 @@ __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
     o[0] = srgb_transfer1(g.x); o[1] = srgb_transfer1(g.y); o[2] = srgb_transfer1(g.z);    // :362-365
 }
 
+// Second half of render_kernel_v2: add the samples of every owned pixel to the HDR buffer IN SAMPLE ORDER
+// (renderer.py:329-330: color_buffer[u, v] += xyzToRGB @ (sample * response * rcp_pdf), one launch per sample).
+// One thread per pixel of an owned tile; item index of (tile k, sample s, lane-pixel sub) = (k*spp + s)*64 + sub.
+__global__ void __launch_bounds__(256) accumulate_kernel(RenderArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = gid >> 6;
+    if (k >= (uint32_t)a.n_tiles) return;
+    const int sub = (int)(gid & 63u);
+    const uint32_t tile = a.tiles[k];
+    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
+    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
+    float* px = a.hdr + ((size_t)v * a.W + u) * 3;
+    float acc_r = px[0], acc_g = px[1], acc_b = px[2];
+    const uint2* c = a.contrib + (size_t)k * 64u * (uint32_t)a.spp_count + sub;
+    for (int s = 0; s < a.spp_count; ++s) {
+        const uint2 q = c[(size_t)s * 64u];
+        const float sample = __builtin_bit_cast(float, q.x);
+        const LambdaNode& L = a.nodes[q.y];
+        vec3 xyz = (sample * v3(L.rx, L.ry, L.rz)) * L.rcp_pdf;
+        vec3 rgb = xyz_to_rgb_d65(xyz);
+        acc_r += rgb.x; acc_g += rgb.y; acc_b += rgb.z;
+    }
+    px[0] = acc_r; px[1] = acc_g; px[2] = acc_b;
+}
+
 // (W, H, 3) view of the [H][W][3] accumulation buffer
 __global__ void hdr_transpose_kernel(const float* hdr, float* out, int W, int H) {
     const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);

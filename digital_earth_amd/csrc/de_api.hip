@@ -114,6 +114,10 @@ struct de_ctx {
     uint32_t* d_tiles = nullptr;
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;
+    uint32_t* d_work_counter = nullptr;
+    uint2* d_contrib = nullptr;  // v2 per-sample contributions
+    size_t contrib_items = 0;
+    int n_cus = 256;
     bool count = false;
     de_counters counters;
     int current_spp = 0;
@@ -210,8 +214,8 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->hdr = c->d_hdr; a->W = c->W; a->H = c->H;
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
-    a->counters = c->d_counters; a->debug_out = c->d_scratch;
-    a->pend_thr = 12; a->tune_a = 0; a->tune_b = 0;
+    a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
+    a->pend_thr = 24; a->tune_a = 0; a->tune_b = 0;
     if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
     if (const char* e = getenv("DE_V2_A")) a->tune_a = atoi(e);
     if (const char* e = getenv("DE_V2_B")) a->tune_b = atoi(e);
@@ -224,8 +228,13 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
     if (!march && c->kernel_variant == 2) {
-        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), grid, block, 0, c->stream, a);
+        // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
+        hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+        const unsigned max_blocks = (unsigned)c->n_cus * 8u;
+        dim3 pgrid(grid.x > max_blocks ? max_blocks : grid.x);
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, block, 0, c->stream, a);
+        if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
         return;
     }
     if (!clamp && !march) hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
@@ -271,12 +280,14 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_fc, sizeof(FrameConsts));
     if (e == hipSuccess) e = hipMalloc(&c->d_nodes, DE_N_NODES * sizeof(LambdaNode));
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * sizeof(uint32_t));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_o3, 441 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_hdr, 0, npx * 3 * sizeof(float), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) {
         std::string msg = std::string("de_create: ") + hipGetErrorString(e);
         de_destroy(c);
@@ -291,7 +302,7 @@ int de_destroy(de_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -383,7 +394,7 @@ int de_reset(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->d_hdr, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     memset(&c->counters, 0, sizeof(c->counters));
     c->current_spp = 0;
     return DE_OK;
@@ -399,6 +410,18 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.spp_begin = c->current_spp; a.spp_count = spp;
+    {   // per-sample contribution buffer of render_kernel_v2 (8 B per sample of this rank's tiles; grows on demand)
+        const size_t need = (size_t)a.n_tiles * 64u * (size_t)(spp > 0 ? spp : 1);
+        if (need >= (size_t)1 << 32) return fail(DE_ERR_INVALID, "spp too large for one launch: split the call (n_tiles*64*spp must be < 2^32)");
+        if (need > c->contrib_items) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_contrib) hipFree(c->d_contrib);
+            c->d_contrib = nullptr; c->contrib_items = 0;
+            HIP_TRY(hipMalloc(&c->d_contrib, need * sizeof(uint2)));
+            c->contrib_items = need;
+        }
+        a.contrib = c->d_contrib;
+    }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (spp > 0 && a.n_tiles > 0) {
         if (c->count) launch_render<1>(c, a); else launch_render<0>(c, a);
@@ -510,12 +533,13 @@ int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVAL
 int de_get_counters(de_ctx* c, de_counters* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof(*out));
     out->samples = h[0]; out->taps_r8 = h[1]; out->taps_rgb8 = h[2]; out->sphere_steps = h[3];
     out->tracking_steps = h[4]; out->vertices = h[5]; out->rng_draws = h[6];
+    for (int i = 0; i < 9; ++i) out->reserved[i] = h[7 + i];   // scheduler statistics of render_kernel_v2 (see its MODE 1 epilogue)
     return DE_OK;
 }
 
@@ -529,6 +553,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.spp_begin = sample_index; a.spp_count = 1;
+    a.contrib = nullptr;
     launch_render<2>(c, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->d_scratch, (size_t)c->W * c->H * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));

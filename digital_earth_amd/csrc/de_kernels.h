@@ -57,6 +57,8 @@ struct RenderArgs {
     int fixed_wavelength;
     unsigned long long* counters; // [8] when counting
     float* debug_out;             // [H][W][4] when tracing single samples
+    uint32_t* work_counter;       // v2: device-wide work-item counter (zeroed before each launch)
+    uint2* contrib;               // v2: per-sample (radiance bits, wavelength node), index = work item
     int pend_thr;                 // v2: lanes that must wait before the transition pass runs
     int tune_a, tune_b;           // v2: spare tuning knobs (env DE_V2_A / DE_V2_B)
 };

@@ -120,6 +120,9 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 
 }  // namespace v2
 
+#ifndef DE_V2_CHUNK
+#define DE_V2_CHUNK 512            // work items a wave takes from the device-wide counter per atomic
+#endif
 #ifndef DE_V2_PENDING_THRESHOLD
 #define DE_V2_PENDING_THRESHOLD 12   // run the transition pass when at least this many lanes wait for it
 #endif
@@ -128,25 +131,29 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 template <bool CLAMP, int MODE>
 __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
     using namespace v2;
-    const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (wave >= a.n_tiles) return;
-    const uint32_t tile = a.tiles[wave];
+    // Persistent waves over WORK ITEMS = single samples.  Item w of the launch is sample (w / 64) % spp of lane-pixel
+    // (w & 63) of owned tile a.tiles[w / (64 * spp)].  A wave takes chunks of DE_V2_CHUNK consecutive items from a
+    // device-wide counter (one atomic per chunk) and hands them to its lanes one by one as paths end, so no lane idles
+    // while work is left and the longest indivisible piece of work is ONE path — not one pixel's 64 samples.
+    // A sample does not touch the HDR buffer: it writes (radiance, wavelength node) to a.contrib[w]; accumulate_kernel
+    // then adds each pixel's samples in index order, ((c + s0) + s1) + ..., exactly like renderer.py:330 does over
+    // successive launches, so the result is bit-identical to one-lane-per-pixel accumulation.
     const int lane = threadIdx.x & 63;
-    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (lane & 7);
-    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (lane >> 3);
-    const uint32_t pixel = (uint32_t)(v * a.W + u);
+    const uint32_t items_per_tile = 64u * (uint32_t)a.spp_count;
+    const uint32_t total_items = (uint32_t)a.n_tiles * items_per_tile;
+    uint32_t w_lo = 0, w_hi = 0;          // wave-uniform: this wave's current chunk [w_lo, w_hi)
+    uint32_t w = 0;                       // this lane's current item
+    int u = 0, v = 0;
+    uint32_t pixel = 0;
     const FrameConsts& fc = *a.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
 
     Work2 wk = {0, 0, 0, 0, 0, 0};
-    float* px = a.hdr + (size_t)pixel * 3;
-    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
-    if (MODE != 2) { acc_r = px[0]; acc_g = px[1]; acc_b = px[2]; }
+    uint32_t n_samples = 0, path_vertices = 0;
 
     // ---- per-lane path state
     Rng rng; rng.s0 = 1; rng.s1 = 0; rng.draws = 0;
     int node = 0;
-    int s_done = 0;                       // samples finished
     vec3 P = v3(0, 0, 0), D = v3(0, 0, 1), LD = v3(0, 0, 1), C = v3(0, 0, 0), N = v3(0, 0, 1);
     float thr = 1.0f, Ls = 0.0f;
     int sc = 0;
@@ -159,13 +166,20 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
     float d0 = 0.0f, alb = 0.0f, ocean = 0.0f, bathy = 0.0f;
     float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f;
     int state = S_NEW;
-    if (a.spp_count <= 0) state = S_DONE;
+    if (a.spp_count <= 0 || a.n_tiles <= 0) state = S_DONE;
 
+    uint32_t st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
     for (;;) {
         const bool tapL = is_tap(state), gasL = is_gas(state);
         const unsigned long long m_tap = __ballot(tapL), m_gas = __ballot(gasL);
         const unsigned long long m_live = __ballot(state != S_DONE);
         if (m_live == 0ull) break;
+        if (MODE == 1) {
+            st_trips++; st_tap_lanes += __popcll(m_tap); st_gas_lanes += __popcll(m_gas);
+            st_tap_trips += (m_tap != 0ull); st_gas_trips += (m_gas != 0ull);
+            st_done_lanes += 64 - __popcll(m_live);
+            st_surf_wait += __popcll(__ballot(state == S_SURF_FINISH || state == S_SURF_SETUP));
+        }
 
         // ============================================================ TAP class
         if (m_tap != 0ull) {
@@ -298,6 +312,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
         const int n_pend = __popcll(m_pend);
         const unsigned long long m_loop = __ballot(is_tap(state) || is_gas(state));
         if (n_pend == 0 || (n_pend < a.pend_thr && m_loop != 0ull)) continue;
+        if (MODE == 1) { st_passes++; st_pend_lanes += n_pend; }
 
         // ---- after a sphere trace (pathtracer.py:46): result, then the gas segment of the same ray
         if (__ballot(state == S_AFTER_ST_P || state == S_AFTER_ST_S) != 0ull) {
@@ -469,25 +484,49 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     Ls += stars_power * L.sun_power * 0.0000001f;
                 }
                 if (__builtin_isinf(Ls) || Ls != Ls || Ls < 0.0f) Ls = 0.0f;
-                vec3 xyz = (Ls * v3(L.rx, L.ry, L.rz)) * L.rcp_pdf;
-                vec3 rgb = xyz_to_rgb_d65(xyz);
-                acc_r += rgb.x; acc_g += rgb.y; acc_b += rgb.z;
+                if (MODE != 2) a.contrib[w] = make_uint2(__builtin_bit_cast(uint32_t, Ls), (uint32_t)node);
                 if (MODE) wk.draws += rng.draws;
                 if (MODE == 2) {
                     float* q = a.debug_out + (size_t)pixel * 4;
-                    q[0] = Ls; q[1] = L.wavelength; q[2] = (float)rng.draws; q[3] = (float)wk.vertices;
+                    q[0] = Ls; q[1] = L.wavelength; q[2] = (float)rng.draws; q[3] = (float)path_vertices;
                 }
-                s_done++;
+                n_samples++;
                 state = S_NEW;
             }
         }
         // ---- next sample of this pixel (renderer.py:305-314)
         if (__ballot(state == S_NEW) != 0ull) {
-            if (state == S_NEW) {
-                if (s_done >= a.spp_count) {
+            // Hand out items of the wave's chunk; refill it (one device-wide atomic) when it runs dry.  Executed by ALL
+            // lanes (wave-uniform branch) so that the chunk bounds w_lo / w_hi stay wave-uniform.
+            const bool need = (state == S_NEW);
+            bool got = false;
+            for (;;) {
+                const unsigned long long m_need = __ballot(need && !got);
+                if (m_need == 0ull) break;
+                const uint32_t avail = w_hi - w_lo;
+                const int my = __popcll(m_need & ((1ull << lane) - 1ull));
+                if (need && !got && (uint32_t)my < avail) { w = w_lo + (uint32_t)my; got = true; }
+                w_lo += min((uint32_t)__popcll(m_need), avail);
+                if (__ballot(need && !got) == 0ull) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.work_counter, (uint32_t)DE_V2_CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= total_items) break;
+                w_lo = base;
+                w_hi = min(base + (uint32_t)DE_V2_CHUNK, total_items);
+            }
+            if (need) {
+                if (!got) {
                     state = S_DONE;
                 } else {
-                    rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_done));
+                    const uint32_t tile = a.tiles[w / items_per_tile];
+                    const uint32_t r = w % items_per_tile;
+                    const int s_idx = (int)(r >> 6);
+                    const int sub = (int)(r & 63u);
+                    u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
+                    v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
+                    pixel = (uint32_t)(v * a.W + u);
+                    rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
                     node = 0;
                     if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];
@@ -495,6 +534,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     D = v2::get_cast_dir(rng, fc, a.H, u, v);
                     P = fc.cam_pos;
                     thr = 1.0f; Ls = 0.0f; sc = 0;
+                    path_vertices = 0;
                     state = S_VERTEX;
                 }
             }
@@ -502,7 +542,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
         // ---- start of a vertex: intersect_land head (pathtracer.py:29-35)
         if (__ballot(state == S_VERTEX) != 0ull) {
             if (state == S_VERTEX) {
-                if (MODE) wk.vertices++;
+                if (MODE) { wk.vertices++; path_vertices++; }
                 vec2_ atmos = rsi(P, D, DE_ATMOS_UPPER);
                 atm_x = atmos.x; atm_y = atmos.y;
                 t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
@@ -513,14 +553,24 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
         }
     }
 
-    if (MODE != 2) { px[0] = acc_r; px[1] = acc_g; px[2] = acc_b; }
     if (MODE == 1) {
-        atomicAdd(&a.counters[0], (unsigned long long)a.spp_count);
+        atomicAdd(&a.counters[0], (unsigned long long)n_samples);
         atomicAdd(&a.counters[1], (unsigned long long)wk.taps_r8);
         atomicAdd(&a.counters[2], (unsigned long long)wk.taps_rgb);
         atomicAdd(&a.counters[3], (unsigned long long)wk.sphere_steps);
         atomicAdd(&a.counters[4], (unsigned long long)wk.tracking_steps);
         atomicAdd(&a.counters[5], (unsigned long long)wk.vertices);
         atomicAdd(&a.counters[6], (unsigned long long)wk.draws);
+        if (lane == 0) {   // per-wave scheduler statistics
+            atomicAdd(&a.counters[7], (unsigned long long)st_trips);
+            atomicAdd(&a.counters[8], (unsigned long long)st_passes);
+            atomicAdd(&a.counters[9], (unsigned long long)st_tap_lanes);
+            atomicAdd(&a.counters[10], (unsigned long long)st_gas_lanes);
+            atomicAdd(&a.counters[11], (unsigned long long)st_pend_lanes);
+            atomicAdd(&a.counters[12], (unsigned long long)st_tap_trips);
+            atomicAdd(&a.counters[13], (unsigned long long)st_gas_trips);
+            atomicAdd(&a.counters[14], (unsigned long long)st_done_lanes);
+            atomicAdd(&a.counters[15], (unsigned long long)st_surf_wait);
+        }
     }
 }

@@ -234,7 +234,8 @@ def test_kernel_variants_agree(Renderer, preset):
         r.reset_framebuffer()
         r.enable_counters(True)
         r.accumulate(3)
-        out[variant] = (r.fetch_hdr(), r.counters(), r.debug_samples(1))
+        cnt = r.counters(); cnt.pop("sched", None)
+        out[variant] = (r.fetch_hdr(), cnt, r.debug_samples(1))
     assert (out[1][0].view(np.uint32) == out[2][0].view(np.uint32)).all()
     assert out[1][1] == out[2][1]
     assert (out[1][2].view(np.uint32) == out[2][2].view(np.uint32)).all()
