@@ -115,6 +115,7 @@ struct de_ctx {
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;
     uint32_t* d_work_counter = nullptr;
+    unsigned int* d_div_fail = nullptr;
     uint2* d_contrib = nullptr;  // v2 per-sample contributions
     size_t contrib_items = 0;
     int n_cus = 256;
@@ -170,6 +171,11 @@ int run_setup(de_ctx* c) {
     s.fc = c->d_fc; s.nodes = c->d_nodes; s.node_val = c->d_node_val;
     hipLaunchKernelGGL(setup_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, s);
     HIP_TRY(hipGetLastError());
+    // prove (exhaustively, on the device) for which wavelength nodes the 3-operation division by the majorant is exact
+    HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
+    hipLaunchKernelGGL(enable_fast_div_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, c->d_nodes, (const unsigned int*)c->d_div_fail);
+    HIP_TRY(hipGetLastError());
     c->params_dirty = false;
     return DE_OK;
 }
@@ -215,9 +221,10 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
-    a->pend_thr = 24; a->tune_a = 0; a->tune_b = 0;
+    a->pend_thr = 24; a->heavy_thr = 12; a->tune_b = 40; a->gas_thr = 8;
+    if (const char* e = getenv("DE_V2_G")) a->gas_thr = atoi(e);
     if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
-    if (const char* e = getenv("DE_V2_A")) a->tune_a = atoi(e);
+    if (const char* e = getenv("DE_V2_A")) a->heavy_thr = atoi(e);
     if (const char* e = getenv("DE_V2_B")) a->tune_b = atoi(e);
     return DE_OK;
 }
@@ -282,6 +289,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_div_fail, DE_N_NODES * sizeof(unsigned int));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
@@ -302,7 +310,7 @@ int de_destroy(de_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_div_fail};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -82,12 +82,13 @@ struct TexF3 {
     int w, h;
 };
 
-DE_DEV float unorm8(uint32_t b) { return (float)b / 255.0f; }
+DE_DEV float unorm8(uint32_t b) { return DE_DIVC((float)b, 255.0f); }   // == (float)b / 255.0f
 
 struct TapCount { uint32_t r8, rgb; };
 
+// A tap in two halves, so that the caller can put independent work between the load and its first use.
 template <bool CLAMP>
-DE_DEV float tap_r8(const TexR8& t, float u, float v) {
+DE_DEV uint32_t tap_r8_issue(const TexR8& t, float u, float v, float* fx_out, float* fy_out) {
     float x = u * t.wf - 0.5f;
     float y = v * t.hf - 0.5f;
     float x0f = de_floor(x), y0f = de_floor(y);
@@ -101,11 +102,20 @@ DE_DEV float tap_r8(const TexR8& t, float u, float v) {
         if (j0 < 0) j0 = t.h - 1;
     }
     uint32_t idx = ((uint32_t)(j0 >> 2) * (uint32_t)t.tiles_x + (uint32_t)(i0 >> 3)) * 32u + (uint32_t)(((j0 & 3) << 3) | (i0 & 7));
-    uint32_t q = t.data[idx];
+    *fx_out = fx; *fy_out = fy;
+    return t.data[idx];
+}
+DE_DEV float tap_r8_finish(uint32_t q, float fx, float fy) {
     float t00 = unorm8(q & 255u), t10 = unorm8((q >> 8) & 255u), t01 = unorm8((q >> 16) & 255u), t11 = unorm8(q >> 24);
     float a = de_fma(t10 - t00, fx, t00);
     float b = de_fma(t11 - t01, fx, t01);
     return de_fma(b - a, fy, a);
+}
+template <bool CLAMP>
+DE_DEV float tap_r8(const TexR8& t, float u, float v) {
+    float fx, fy;
+    uint32_t q = tap_r8_issue<CLAMP>(t, u, v, &fx, &fy);
+    return tap_r8_finish(q, fx, fy);
 }
 DE_DEV int wrap_idx(int i, int n, bool clamp) {
     if (clamp) return i < 0 ? 0 : (i >= n ? n - 1 : i);
@@ -169,8 +179,8 @@ DE_DEV vec2_ rsi(vec3 pos, vec3 dir, float r) {
 }
 DE_DEV vec2_ sphere_UV_map(vec3 n) {                                                                   // :25-28
     vec2_ o;
-    o.x = (de_atan2(n.z, -n.x) / (float)M_PI + 1.0f) / 2.0f;
-    o.y = de_asin(n.y) / (float)M_PI + 0.5f;
+    o.x = (DE_DIVC(de_atan2(n.z, -n.x), (float)M_PI) + 1.0f) / 2.0f;
+    o.y = DE_DIVC(de_asin(n.y), (float)M_PI) + 0.5f;
     return o;
 }
 DE_DEV float fract_(float x) { return x - de_floor(x); }
@@ -348,7 +358,7 @@ DE_DEV float get_ozone_density(float h) {                                       
     float h_km = h * 0.001f;
     float rel = h_km - (float)(25000.0 * 0.001);
     rel = rel * rel;
-    float d = (float)(1.0 - 0.375) * de_exp(-rel / 49.0f);
+    float d = (float)(1.0 - 0.375) * de_exp(DE_DIVC(-rel, 49.0f));
     d += 0.375f * de_exp(-rel / 256.0f);
     float t = h_km - 15.0f;
     d += de_max(0.0f, -0.000015f * (t * t * t));
@@ -356,14 +366,14 @@ DE_DEV float get_ozone_density(float h) {                                       
 }
 DE_DEV float get_rayl_density(float h) {                                                               // :249-253
     float t = h + 24239.99f;
-    return 3.68082f * de_exp(-(t * t) / 532307548.4168f) / 1.225f;
+    return DE_DIVC(3.68082f * de_exp(DE_DIVC(-(t * t), 532307548.4168f)), 1.225f);
 }
 DE_DEV float get_mie_density(float h) {                                                                // :255-268
     float dens;
     if (h > 11500.0f)      { float t = h - 11500.0f; dens = 0.0918f * de_exp(-1.0e-6f * (t * t)); }
     else if (h > 2400.0f)  { float t = h + 2500.0f;  dens = 0.3000f * de_exp(-2.5e-9f * (t * t)) - 0.092f; }
     else if (h > 1300.0f)  { float t = h - 1300.0f;  dens = 0.6500f * de_exp(-5.0e-6f * (t * t)) + 0.18899f; }
-    else                   { dens = 1.0f - h / 8136.646f; }
+    else                   { dens = 1.0f - DE_DIVC(h, 8136.646f); }
     return dens * (float)1.06;
 }
 DE_DEV vec3 get_density(float h) {                                                                     // :271-274

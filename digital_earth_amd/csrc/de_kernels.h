@@ -39,6 +39,9 @@ struct LambdaNode {
     float max_ext_rmo;       //                                  pathtracer.py:355
     float c0, c1, c2;        // srgb_to_spectrum coefficients mix(lut[w], lut[w+1], f)   lib/colour.py:64-70
     float s2s_valid;         // 1 if 0 < w < 299 else 0
+    float inv_max_ext_rmo;   // RN(1 / max_ext_rmo)
+    float fast_div;          // 1 if x / max_ext_rmo == de_div_rc(x, max_ext_rmo, inv) for every significand of x (checked on the device)
+    float pad0, pad1;
 };
 #define DE_N_NODES 512
 
@@ -60,7 +63,9 @@ struct RenderArgs {
     uint32_t* work_counter;       // v2: device-wide work-item counter (zeroed before each launch)
     uint2* contrib;               // v2: per-sample (radiance bits, wavelength node), index = work item
     int pend_thr;                 // v2: lanes that must wait before the transition pass runs
-    int tune_a, tune_b;           // v2: spare tuning knobs (env DE_V2_A / DE_V2_B)
+    int heavy_thr;                // v2: stashed paths of one kind that trigger a batch (env DE_V2_A)
+    int gas_thr;                  // v2: lanes waiting in the GAS class that make its body run (env DE_V2_G)
+    int tune_b;                   // v2: below this many iterating lanes everything that waits is processed (env DE_V2_B)
 };
 
 struct SetupArgs {

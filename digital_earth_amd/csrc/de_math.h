@@ -26,6 +26,22 @@ DE_DEV float de_min(float a, float b) { return (b < a) ? b : a; }
 DE_DEV float de_clamp(float x, float lo, float hi) { return de_min(de_max(x, lo), hi); }
 DE_DEV float de_saturate(float x) { return de_clamp(x, 0.0f, 1.0f); }
 
+// x / c in 3 operations instead of the ~12 of an IEEE divide, for a divisor whose reciprocal rc = RN(1/c) is known.
+// That q below IS the correctly rounded x / c is a property of the divisor: tools/verify_exact_div.c checks it
+// exhaustively (all 2^23 significands) for every literal divisor used in this file set, and setup_kernel checks it on
+// the device for the per-wavelength majorants before enabling it (LambdaNode::fast_div).  Outside
+// 2^-100 <= |x| <= 2^100 (zeros, subnormal residuals, inf, NaN) the real divide runs — a branch no lane normally takes.
+DE_DEV float de_div_rc(float x, float c, float rc) {
+    float q0 = x * rc;
+    float r = de_fma(-q0, c, x);
+    float q = de_fma(r, rc, q0);
+    float ax = de_abs(x);
+    // zero takes the short path too (0 * rc = 0 exactly; only the sign of a -0 quotient differs, which no caller observes)
+    if (__builtin_expect(!(ax >= 0x1p-100f && ax <= 0x1p+100f) && ax != 0.0f, 0)) q = x / c;
+    return q;
+}
+#define DE_DIVC(x, c) de_div_rc((x), (c), 1.0f / (c))
+
 #define DE_PI 0x1.921fb6p+1f
 #define DE_PIO2 0x1.921fb6p+0f
 #define DE_LN2_HI 0x1.63p-1f

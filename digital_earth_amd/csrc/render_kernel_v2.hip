@@ -123,6 +123,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #ifndef DE_V2_CHUNK
 #define DE_V2_CHUNK 512            // work items a wave takes from the device-wide counter per atomic
 #endif
+#define DE_V2_STASH_FIELDS 33
 #ifndef DE_V2_PENDING_THRESHOLD
 #define DE_V2_PENDING_THRESHOLD 12   // run the transition pass when at least this many lanes wait for it
 #endif
@@ -143,8 +144,6 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
     const uint32_t total_items = (uint32_t)a.n_tiles * items_per_tile;
     uint32_t w_lo = 0, w_hi = 0;          // wave-uniform: this wave's current chunk [w_lo, w_hi)
     uint32_t w = 0;                       // this lane's current item
-    int u = 0, v = 0;
-    uint32_t pixel = 0;
     const FrameConsts& fc = *a.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
 
@@ -164,15 +163,38 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
     int rmo_event = 0, ev_id = 0;         // ev_id: interaction id of the resolved event
     float li = -1.0f;                     // land_isection argument of the light-sample transmittance
     float d0 = 0.0f, alb = 0.0f, ocean = 0.0f, bathy = 0.0f;
-    float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f;
+    float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f, rmaxr = 0.0f;   // rmaxr = 1/maxr when the 3-op division is proven exact, else 0
     int state = S_NEW;
     if (a.spp_count <= 0 || a.n_tiles <= 0) state = S_DONE;
 
-    uint32_t st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
+    // ---- second path slot per lane ("stash", LDS).  The three expensive transitions — volume-vertex finish
+    // (phase evaluation + sampling), surface set-up (material taps + grading) and surface finish (two BRDF
+    // evaluations) — cost 600-1300 instructions each and a wave meets each of them less than once per trip: run
+    // in place they execute for 1-2 lanes of 64.  Instead a path that reaches one of them is put aside in the
+    // lane's stash and the lane starts (or resumes) another path; when >= a.heavy_thr lanes of the wave hold a
+    // stashed path waiting for the same transition, those lanes swap the stashed path in, run the transition
+    // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
+    // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
+    __shared__ uint32_t s_stash[4][DE_V2_STASH_FIELDS][64];
+    uint32_t* const slot = &s_stash[threadIdx.x >> 6][0][lane];
+    int stash = 0;                        // 0 empty; 1/2/3 waiting for S_SC_FINISH / S_SURF_SETUP / S_SURF_FINISH; 4 ready to resume
+#define DE_XF(i, var) { const uint32_t tmp_ = slot[(i) * 64]; slot[(i) * 64] = __builtin_bit_cast(uint32_t, var); var = __builtin_bit_cast(decltype(var), tmp_); }
+#define DE_EXCHANGE_PATH()                                                                                              \
+    { DE_XF(0, P.x) DE_XF(1, P.y) DE_XF(2, P.z) DE_XF(3, D.x) DE_XF(4, D.y) DE_XF(5, D.z) DE_XF(6, LD.x) DE_XF(7, LD.y)   \
+      DE_XF(8, LD.z) DE_XF(9, N.x) DE_XF(10, N.y) DE_XF(11, N.z) DE_XF(12, thr) DE_XF(13, Ls) DE_XF(14, trg) DE_XF(15, trn) \
+      DE_XF(16, alb) DE_XF(17, ocean) DE_XF(18, bathy) DE_XF(19, li) DE_XF(20, atm_x) DE_XF(21, atm_y) DE_XF(22, t)       \
+      DE_XF(23, sc) DE_XF(24, rng.s0) DE_XF(25, rng.s1) DE_XF(26, rng.draws) DE_XF(27, node) DE_XF(28, w) DE_XF(29, ev_id) \
+      DE_XF(30, state) DE_XF(31, path_vertices) DE_XF(32, cnt) }
+#define DE_RELOAD_NODE()                                                                                                \
+    { const LambdaNode& Ln_ = a.nodes[node]; ext_r = Ln_.ext_r; ext_m = Ln_.ext_m; ext_o = Ln_.ext_o; maxr = Ln_.max_ext_rmo; \
+      rmaxr = (Ln_.fast_div != 0.0f) ? Ln_.inv_max_ext_rmo : 0.0f; }
+
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = (MODE == 1) ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t st_batches = 0, st_batch_lanes = 0, st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
     for (;;) {
         const bool tapL = is_tap(state), gasL = is_gas(state);
         const unsigned long long m_tap = __ballot(tapL), m_gas = __ballot(gasL);
-        const unsigned long long m_live = __ballot(state != S_DONE);
+        const unsigned long long m_live = __ballot(state != S_DONE || stash != 0);
         if (m_live == 0ull) break;
         if (MODE == 1) {
             st_trips++; st_tap_lanes += __popcll(m_tap); st_gas_lanes += __popcll(m_gas);
@@ -181,22 +203,28 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
             st_surf_wait += __popcll(__ballot(state == S_SURF_FINISH || state == S_SURF_SETUP));
         }
 
-        // ============================================================ TAP class
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
+        // ============================================================ TAP class, first half: position, UV, issue the tap
+        // The map tap is the long-latency operation of a trip (L2 / HBM).  It is issued here, the GAS class runs
+        // while it is in flight, and the texel is consumed in the second half below.
+        uint32_t tap_q = 0;
+        float tap_fx = 0.0f, tap_fy = 0.0f, tap_len = 0.0f;
+        bool tap_alive = false, tap_do = false;
         if (m_tap != 0ull) {
             if (tapL) {
                 const bool cloud = is_cloud_tap(state);
                 const vec3 W = (state == S_ST_P || state == S_DT_C) ? D : LD;
-                bool alive = true;
                 vec3 Q;
-                float maxc = 0.0f, ext_w = 0.0f;
+                tap_alive = true;
                 if (cloud) {
-                    ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
-                    maxc = ext_w * DE_CLOUDS_DENSITY;
-                    float t_step = -de_log(rng_next(rng)) / maxc;
+                    const float ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
+                    const float maxc = ext_w * DE_CLOUDS_DENSITY;
+                    const float rmaxc = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
+                    float t_step = de_div_rc(-de_log(rng_next(rng)), maxc, rmaxc);
                     C = C + t_step * W;
                     t += t_step;
                     if (MODE) wk.tracking_steps++;
-                    alive = !(t >= tmax);
+                    tap_alive = !(t >= tmax);
                     Q = C;
                 } else if (state <= S_ST_S) {
                     Q = P + W * t;
@@ -207,38 +235,100 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     if (state == S_NRM2) Q = P - v3(0.0f, e, 0.0f);
                     if (state == S_NRM3) Q = P - v3(0.0f, 0.0f, e);
                 }
-                if (alive) {
-                    const float len = length(Q);
-                    const bool do_tap = !cloud || (len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER);
-                    float tex = 0.0f;
-                    if (do_tap) {
-                        const vec3 n = Q / len;
+                if (tap_alive) {
+                    tap_len = length(Q);
+                    tap_do = !cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER);
+                    if (tap_do) {
+                        const vec3 n = Q / tap_len;
                         if (MODE) wk.taps_r8++;
-                        // per-lane map select (two maps only in this class)
-                        TexR8 T;
+                        TexR8 T;   // per-lane map select (two maps only in this class)
                         T.data = cloud ? a.clouds.data : a.topo.data;
                         T.w = cloud ? a.clouds.w : a.topo.w; T.h = cloud ? a.clouds.h : a.topo.h;
                         T.tiles_x = cloud ? a.clouds.tiles_x : a.topo.tiles_x;
                         T.wf = cloud ? a.clouds.wf : a.topo.wf; T.hf = cloud ? a.clouds.hf : a.topo.hf;
-                        tex = sphere_tap_r8<CLAMP>(T, n);
+                        vec2_ uv = sphere_UV_map(n);
+                        tap_q = tap_r8_issue<CLAMP>(T, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &tap_fx, &tap_fy);
                     }
+                }
+            }
+        }
+
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[1] += now_ - tlast; tlast = now_; }
+        // ============================================================ GAS class
+        // runs when enough lanes wait in it (a.gas_thr) or the TAP class is short of lanes
+        if (m_gas != 0ull && (__popcll(m_gas) >= a.gas_thr || __popcll(m_tap) < 24)) {
+            if (gasL) {
+                const vec3 W = (state == S_DT_G) ? D : LD;
+                // x / maxr: 3 operations where the device-side proof passed for this wavelength (LambdaNode::fast_div), else the divide
+                auto gas_div = [&](float x) -> float { return (rmaxr != 0.0f) ? de_div_rc(x, maxr, rmaxr) : x / maxr; };
+                float t_step = gas_div(-de_log(rng_next(rng)));
+                C = C + t_step * W;
+                t += t_step;
+                if (MODE) wk.tracking_steps++;
+                if (t >= tmax) {
+                    if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
+                    else { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                } else {
+                    vec3 dens = get_density(de_sqrt((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
+                    vec3 es = v3(ext_r, ext_m, ext_o) * dens;
+                    float sum = (es.x + es.y) + es.z;
+                    if (state == S_DT_G) {
+                        float rand = rng_next(rng);
+                        if (rand < gas_div(sum)) {
+                            int id = 0;
+                            float cmf = es.x;
+                            if (!(rand < gas_div(cmf))) {
+                                id = 1;
+                                cmf += es.y;
+                                if (!(rand < gas_div(cmf))) {
+                                    id = 2;
+                                    cmf += es.z;
+                                    if (!(rand < gas_div(cmf))) id = 3;
+                                }
+                            }
+                            const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));
+                            rmo_event = (rng_next(rng) < albedo) ? EV_SCATTER : EV_ABSORB;
+                            rmo_t = t;
+                            ev_id = id;
+                            state = S_CLOUD_SETUP_DT;
+                        }
+                    } else {
+                        trn *= 1.0f - gas_div(sum);
+                        if (trn < 1e-5f) { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                    }
+                }
+            }
+        }
+
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[2] += now_ - tlast; tlast = now_; }
+        // ============================================================ TAP class, second half: consume the texel
+        if (m_tap != 0ull) {
+            if (tapL) {
+                const bool cloud = is_cloud_tap(state);
+                if (tap_alive) {
+                    const float len = tap_len;
+                    float tex = 0.0f;
+                    if (tap_do) tex = tap_r8_finish(tap_q, tap_fx, tap_fy);
                     if (cloud) {
+                        const float ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
+                        const float maxc = ext_w * DE_CLOUDS_DENSITY;
+                        const float rmaxc = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
                         // get_clouds_density, pathtracer.py:48-65
                         float density = 0.0f;
-                        if (do_tap) {
-                            float h = (len - DE_CLOUDS_LOWER) / DE_CLOUDS_THICKNESS;
+                        if (tap_do) {
+                            float h = DE_DIVC(len - DE_CLOUDS_LOWER, DE_CLOUDS_THICKNESS);
                             const float split = 0.2f;
                             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
                         }
                         float es = ext_w * (density * DE_CLOUDS_DENSITY);
                         if (state == S_DT_C) {
                             float rand = rng_next(rng);
-                            if (rand < es / maxc) {
+                            if (rand < de_div_rc(es, maxc, rmaxc)) {
                                 rmo_event |= ((rng_next(rng) < 0.99f) ? EV_SCATTER : EV_ABSORB) << 4;   // cloud event in bits 4-5
                                 state = S_AFTER_DT_C;
                             }
                         } else {
-                            trn *= 1.0f - es / maxc;
+                            trn *= 1.0f - de_div_rc(es, maxc, rmaxc);
                             if (trn < 1e-5f) state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
                         }
                     } else {
@@ -264,56 +354,20 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
             }
         }
 
-        // ============================================================ GAS class
-        if (m_gas != 0ull) {
-            if (gasL) {
-                const vec3 W = (state == S_DT_G) ? D : LD;
-                float t_step = -de_log(rng_next(rng)) / maxr;
-                C = C + t_step * W;
-                t += t_step;
-                if (MODE) wk.tracking_steps++;
-                if (t >= tmax) {
-                    if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
-                    else { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
-                } else {
-                    vec3 dens = get_density(de_sqrt((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
-                    vec3 es = v3(ext_r, ext_m, ext_o) * dens;
-                    float sum = (es.x + es.y) + es.z;
-                    if (state == S_DT_G) {
-                        float rand = rng_next(rng);
-                        if (rand < sum / maxr) {
-                            int id = 0;
-                            float cmf = es.x;
-                            if (!(rand < cmf / maxr)) {
-                                id = 1;
-                                cmf += es.y;
-                                if (!(rand < cmf / maxr)) {
-                                    id = 2;
-                                    cmf += es.z;
-                                    if (!(rand < cmf / maxr)) id = 3;
-                                }
-                            }
-                            const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));
-                            rmo_event = (rng_next(rng) < albedo) ? EV_SCATTER : EV_ABSORB;
-                            rmo_t = t;
-                            ev_id = id;
-                            state = S_CLOUD_SETUP_DT;
-                        }
-                    } else {
-                        trn *= 1.0f - sum / maxr;
-                        if (trn < 1e-5f) { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
-                    }
-                }
-            }
-        }
-
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[1] += now_ - tlast; tlast = now_; }
         // ============================================================ transitions
-        const unsigned long long m_pend = __ballot(state >= S_AFTER_ST_P && state != S_DONE);
-        const int n_pend = __popcll(m_pend);
-        const unsigned long long m_loop = __ballot(is_tap(state) || is_gas(state));
-        if (n_pend == 0 || (n_pend < a.pend_thr && m_loop != 0ull)) continue;
+        const bool heavyA = (state >= S_SC_FINISH && state <= S_SURF_FINISH);
+        const bool parked = heavyA && stash >= 1 && stash <= 3;          // both of the lane's paths wait for a batch
+        const bool pendL = (state >= S_AFTER_ST_P && state != S_DONE && !parked) || (state == S_DONE && stash == 4);
+        const int n_pend = __popcll(__ballot(pendL));
+        const int n_loop = __popcll(__ballot(is_tap(state) || is_gas(state)));
+        const int n_w1 = __popcll(__ballot(stash == 1)), n_w2 = __popcll(__ballot(stash == 2)), n_w3 = __popcll(__ballot(stash == 3));
+        const bool flush_all = n_loop < a.tune_b;                        // too few lanes iterating: process everything that waits
+        const bool batch_due = (n_w1 >= a.heavy_thr) || (n_w2 >= a.heavy_thr) || (n_w3 >= a.heavy_thr);
+        if (!(n_pend >= a.pend_thr || batch_due || (flush_all && (n_pend > 0 || n_w1 + n_w2 + n_w3 > 0)))) continue;
         if (MODE == 1) { st_passes++; st_pend_lanes += n_pend; }
 
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
         // ---- after a sphere trace (pathtracer.py:46): result, then the gas segment of the same ray
         if (__ballot(state == S_AFTER_ST_P || state == S_AFTER_ST_S) != 0ull) {
             if (state == S_AFTER_ST_P || state == S_AFTER_ST_S) {
@@ -395,83 +449,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                 }
             }
         }
-        // ---- volume vertex: in-scattering, phase sampling, roulette (pathtracer.py:394-401, 448-453)
-        if (__ballot(state == S_SC_FINISH) != 0ull) {
-            if (state == S_SC_FINISH) {
-                const LambdaNode& L = a.nodes[node];
-                const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
-                const float direct_phase = evaluate_phase(fc, D, LD, ev_id, sc > 0);
-                Ls += thr * direct_tr * L.sun_irradiance * direct_phase;
-                float phase_div_pdf;
-                vec3 nd = sample_phase(fc, rng, D, ev_id, sc > 0, &phase_div_pdf);
-                D = nd;
-                thr *= phase_div_pdf;
-                state = S_VERTEX;
-                if (sc > 3) {
-                    float termination_p = de_max(0.05f, 1.0f - thr);
-                    if (rng_next(rng) < termination_p) state = S_END;
-                    else thr /= 1.0f - termination_p;
-                }
-                sc++;
-                if (state == S_VERTEX && sc >= 25) state = S_END;
-            }
-        }
-        // ---- surface vertex, first half: normal, material, emissive, shadow-ray set-up (pathtracer.py:406-422)
-        if (__ballot(state == S_SURF_SETUP) != 0ull) {
-            if (state == S_SURF_SETUP) {
-                const LambdaNode& L = a.nodes[node];
-                N = normalized(N);
-                vec3 n = normalized(P);
-                vec2_ uv = sphere_UV_map(n);
-                float uu = fract_(uv.x * 1.0f), vv = fract_(uv.y * 1.0f);
-                ocean = tap_r8<CLAMP>(a.ocean, uu, vv);
-                vec3 tex = tap_rgb<CLAMP>(a.albedo, uu, vv);
-                vec3 land = mix3(lum3(tex), tex, 6.5f);
-                float greenery = sqr(land.y / lum(land));
-                greenery = smoothstep_(1.5f, 1.9f, greenery);
-                land = (1.0f * tex) / (greenery * 0.7f + 1.0f);
-                land = mix3(lum3(land), land, 1.4f - greenery * 0.45f);
-                land = mix3(land, (land * v3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));
-                vec3 ocean_albedo = mix3(lum3(tex), tex, 0.75f) * 0.9f;
-                vec3 albedo_srgb = mix3(land, ocean_albedo, ocean);
-                bathy = tap_r8<CLAMP>(a.bathy, uu, vv);
-                float emissive = tap_r8<CLAMP>(a.emissive, uu, vv);
-                if (MODE) { wk.taps_r8 += 3; wk.taps_rgb += 1; }
-                alb = srgb_to_spectrum(L, albedo_srgb);
-                Ls += thr * emissive * L.night_power;
-                P = P * fc.offset_scale;                                 // offset_pos
-                // intersect_land(offset_pos, light_dir) head
-                vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
-                atm_x = atmos.x; atm_y = atmos.y;
-                t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
-                cnt = 0;
-                state = S_ST_S;
-            }
-        }
-        // ---- surface vertex, second half: direct light, bounce, roulette (pathtracer.py:431-439, 448-453)
-        if (__ballot(state == S_SURF_FINISH) != 0ull) {
-            if (state == S_SURF_FINISH) {
-                const LambdaNode& L = a.nodes[node];
-                const float direct_tr = trg * trn;
-                const bool visible = li < 0.0f;
-                float direct_ndl;
-                float direct_brdf = earth_brdf(alb, ocean, bathy, -D, N, LD, &direct_ndl);
-                Ls += thr * direct_tr * (visible ? 1.0f : 0.0f) * L.sun_irradiance * direct_brdf * direct_ndl;
-                vec3 view_dir = -D;
-                D = sample_hemisphere_cosine_weighted(rng, N);
-                float unused;
-                float brdf = earth_brdf(alb, ocean, bathy, view_dir, N, D, &unused);
-                thr *= brdf * (float)M_PI;
-                state = S_VERTEX;
-                if (sc > 3) {
-                    float termination_p = de_max(0.05f, 1.0f - thr);
-                    if (rng_next(rng) < termination_p) state = S_END;
-                    else thr /= 1.0f - termination_p;
-                }
-                sc++;
-                if (state == S_VERTEX && sc >= 25) state = S_END;
-            }
-        }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[3] += now_ - tlast; tlast = now_; }
         // ---- end of path: miss epilogue, NaN guard, colour accumulation (pathtracer.py:455-469, renderer.py:329-330)
         if (__ballot(state == S_END || state == S_END_MISS) != 0ull) {
             if (state == S_END || state == S_END_MISS) {
@@ -487,13 +465,137 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                 if (MODE != 2) a.contrib[w] = make_uint2(__builtin_bit_cast(uint32_t, Ls), (uint32_t)node);
                 if (MODE) wk.draws += rng.draws;
                 if (MODE == 2) {
-                    float* q = a.debug_out + (size_t)pixel * 4;
+                    const uint32_t tile_ = a.tiles[w / items_per_tile];
+                    const int sub_ = (int)((w % items_per_tile) & 63u);
+                    const uint32_t pixel_ = (uint32_t)(((int)(tile_ / (uint32_t)a.tiles_x) * 8 + (sub_ >> 3)) * a.W + (int)(tile_ % (uint32_t)a.tiles_x) * 8 + (sub_ & 7));
+                    float* q = a.debug_out + (size_t)pixel_ * 4;
                     q[0] = Ls; q[1] = L.wavelength; q[2] = (float)rng.draws; q[3] = (float)path_vertices;
                 }
                 n_samples++;
                 state = S_NEW;
             }
         }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[4] += now_ - tlast; tlast = now_; }
+        // ---- a path reached an expensive transition: put it aside (or swap with the lane's resumable path)
+        if (__ballot(state >= S_SC_FINISH && state <= S_SURF_FINISH) != 0ull) {
+            if (state >= S_SC_FINISH && state <= S_SURF_FINISH && (stash == 0 || stash == 4)) {
+                const int kind = state - S_SC_FINISH + 1;
+                const bool resume = (stash == 4);
+                DE_EXCHANGE_PATH()
+                stash = kind;
+                if (resume) { DE_RELOAD_NODE() }      // `state` is now the resumed path's
+                else state = S_NEW;                   // slot held nothing: start a new path
+            }
+        }
+        // ---- batches of the expensive transitions on the stashed paths
+        {
+            const int c1 = __popcll(__ballot(stash == 1)), c2 = __popcll(__ballot(stash == 2)), c3 = __popcll(__ballot(stash == 3));
+            const int n_loop2 = __popcll(__ballot(is_tap(state) || is_gas(state)));
+            const bool flush = n_loop2 < a.tune_b;
+            const bool run1 = c1 >= a.heavy_thr || (flush && c1 > 0);
+            const bool run2 = c2 >= a.heavy_thr || (flush && c2 > 0);
+            const bool run3 = c3 >= a.heavy_thr || (flush && c3 > 0);
+            const bool in_batch = (stash == 1 && run1) || (stash == 2 && run2) || (stash == 3 && run3);
+            if (run1 || run2 || run3) {
+                if (MODE == 1) { st_batches++; st_batch_lanes += __popcll(__ballot(in_batch)); }
+                if (in_batch) { DE_EXCHANGE_PATH() }  // stashed path in, current path out
+                const bool do1 = run1 && state == S_SC_FINISH, do2 = run2 && state == S_SURF_SETUP, do3 = run3 && state == S_SURF_FINISH;
+                // ---- volume vertex: in-scattering, phase sampling, roulette (pathtracer.py:394-401, 448-453)
+                if (__ballot(do1) != 0ull) {
+                    if (do1) {
+                        const LambdaNode& L = a.nodes[node];
+                        const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
+                        const float direct_phase = evaluate_phase(fc, D, LD, ev_id, sc > 0);
+                        Ls += thr * direct_tr * L.sun_irradiance * direct_phase;
+                        float phase_div_pdf;
+                        vec3 nd = sample_phase(fc, rng, D, ev_id, sc > 0, &phase_div_pdf);
+                        D = nd;
+                        thr *= phase_div_pdf;
+                        state = S_VERTEX;
+                        if (sc > 3) {
+                            float termination_p = de_max(0.05f, 1.0f - thr);
+                            if (rng_next(rng) < termination_p) state = S_END;
+                            else thr /= 1.0f - termination_p;
+                        }
+                        sc++;
+                        if (state == S_VERTEX && sc >= 25) state = S_END;
+                    }
+                }
+                // ---- surface vertex, first half: normal, material, emissive, shadow-ray set-up (pathtracer.py:406-422)
+                if (__ballot(do2) != 0ull) {
+                    if (do2) {
+                        const LambdaNode& L = a.nodes[node];
+                        N = normalized(N);
+                        vec3 n = normalized(P);
+                        vec2_ uv = sphere_UV_map(n);
+                        float uu = fract_(uv.x * 1.0f), vv = fract_(uv.y * 1.0f);
+                        ocean = tap_r8<CLAMP>(a.ocean, uu, vv);
+                        vec3 tex = tap_rgb<CLAMP>(a.albedo, uu, vv);
+                        vec3 land = mix3(lum3(tex), tex, 6.5f);
+                        float greenery = sqr(land.y / lum(land));
+                        greenery = smoothstep_(1.5f, 1.9f, greenery);
+                        land = (1.0f * tex) / (greenery * 0.7f + 1.0f);
+                        land = mix3(lum3(land), land, 1.4f - greenery * 0.45f);
+                        land = mix3(land, (land * v3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));
+                        vec3 ocean_albedo = mix3(lum3(tex), tex, 0.75f) * 0.9f;
+                        vec3 albedo_srgb = mix3(land, ocean_albedo, ocean);
+                        bathy = tap_r8<CLAMP>(a.bathy, uu, vv);
+                        float emissive = tap_r8<CLAMP>(a.emissive, uu, vv);
+                        if (MODE) { wk.taps_r8 += 3; wk.taps_rgb += 1; }
+                        alb = srgb_to_spectrum(L, albedo_srgb);
+                        Ls += thr * emissive * L.night_power;
+                        P = P * fc.offset_scale;                                 // offset_pos
+                        // intersect_land(offset_pos, light_dir) head
+                        vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
+                        atm_x = atmos.x; atm_y = atmos.y;
+                        t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
+                        cnt = 0;
+                        state = S_ST_S;
+                    }
+                }
+                // ---- surface vertex, second half: direct light, bounce, roulette (pathtracer.py:431-439, 448-453)
+                if (__ballot(do3) != 0ull) {
+                    if (do3) {
+                        const LambdaNode& L = a.nodes[node];
+                        const float direct_tr = trg * trn;
+                        const bool visible = li < 0.0f;
+                        float direct_ndl;
+                        float direct_brdf = earth_brdf(alb, ocean, bathy, -D, N, LD, &direct_ndl);
+                        Ls += thr * direct_tr * (visible ? 1.0f : 0.0f) * L.sun_irradiance * direct_brdf * direct_ndl;
+                        vec3 view_dir = -D;
+                        D = sample_hemisphere_cosine_weighted(rng, N);
+                        float unused;
+                        float brdf = earth_brdf(alb, ocean, bathy, view_dir, N, D, &unused);
+                        thr *= brdf * (float)M_PI;
+                        state = S_VERTEX;
+                        if (sc > 3) {
+                            float termination_p = de_max(0.05f, 1.0f - thr);
+                            if (rng_next(rng) < termination_p) state = S_END;
+                            else thr /= 1.0f - termination_p;
+                        }
+                        sc++;
+                        if (state == S_VERTEX && sc >= 25) state = S_END;
+                    }
+                }
+
+                if (in_batch) { DE_EXCHANGE_PATH() stash = 4; }   // processed path back to the slot, resumable
+            }
+        }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[5] += now_ - tlast; tlast = now_; }
+        // ---- resume a processed path where the lane has nothing else to run
+        if (__ballot(stash == 4 && (state == S_NEW || state == S_DONE || (state >= S_SC_FINISH && state <= S_SURF_FINISH))) != 0ull) {
+            if (stash == 4 && (state == S_NEW || state == S_DONE)) {
+                DE_EXCHANGE_PATH()                    // the slot's content is dead afterwards
+                stash = 0;
+                DE_RELOAD_NODE()
+            } else if (stash == 4 && state >= S_SC_FINISH && state <= S_SURF_FINISH) {
+                const int kind = state - S_SC_FINISH + 1;
+                DE_EXCHANGE_PATH()
+                stash = kind;
+                DE_RELOAD_NODE()
+            }
+        }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[5] += now_ - tlast; tlast = now_; }
         // ---- next sample of this pixel (renderer.py:305-314)
         if (__ballot(state == S_NEW) != 0ull) {
             // Hand out items of the wave's chunk; refill it (one device-wide atomic) when it runs dry.  Executed by ALL
@@ -523,14 +625,15 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     const uint32_t r = w % items_per_tile;
                     const int s_idx = (int)(r >> 6);
                     const int sub = (int)(r & 63u);
-                    u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
-                    v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
-                    pixel = (uint32_t)(v * a.W + u);
+                    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
+                    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
+                    const uint32_t pixel = (uint32_t)(v * a.W + u);
                     rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
                     node = 0;
                     if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];
                     ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; maxr = L.max_ext_rmo;
+                    rmaxr = (L.fast_div != 0.0f) ? L.inv_max_ext_rmo : 0.0f;
                     D = v2::get_cast_dir(rng, fc, a.H, u, v);
                     P = fc.cam_pos;
                     thr = 1.0f; Ls = 0.0f; sc = 0;
@@ -539,6 +642,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                 }
             }
         }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[6] += now_ - tlast; tlast = now_; }
         // ---- start of a vertex: intersect_land head (pathtracer.py:29-35)
         if (__ballot(state == S_VERTEX) != 0ull) {
             if (state == S_VERTEX) {
@@ -551,6 +655,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                 state = S_ST_P;
             }
         }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[7] += now_ - tlast; tlast = now_; }
     }
 
     if (MODE == 1) {
@@ -561,16 +666,10 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
         atomicAdd(&a.counters[4], (unsigned long long)wk.tracking_steps);
         atomicAdd(&a.counters[5], (unsigned long long)wk.vertices);
         atomicAdd(&a.counters[6], (unsigned long long)wk.draws);
-        if (lane == 0) {   // per-wave scheduler statistics
+        if (lane == 0) {   // per-wave scheduler statistics: trips, passes, section cycle counters (s_memtime)
             atomicAdd(&a.counters[7], (unsigned long long)st_trips);
             atomicAdd(&a.counters[8], (unsigned long long)st_passes);
-            atomicAdd(&a.counters[9], (unsigned long long)st_tap_lanes);
-            atomicAdd(&a.counters[10], (unsigned long long)st_gas_lanes);
-            atomicAdd(&a.counters[11], (unsigned long long)st_pend_lanes);
-            atomicAdd(&a.counters[12], (unsigned long long)st_tap_trips);
-            atomicAdd(&a.counters[13], (unsigned long long)st_gas_trips);
-            atomicAdd(&a.counters[14], (unsigned long long)st_done_lanes);
-            atomicAdd(&a.counters[15], (unsigned long long)st_surf_wait);
+            for (int i = 0; i < 7; ++i) atomicAdd(&a.counters[9 + i], tm[i] + (i == 6 ? tm[7] : 0ull));
         }
     }
 }
