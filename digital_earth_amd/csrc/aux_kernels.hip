@@ -360,6 +360,8 @@ __global__ void math_kernel(int fn, const float* a, const float* b, float* out, 
         case 6: r = de_pow(x, y); break;
         case 7: r = x / y; break;
         case 8: r = de_sqrt(x); break;
+        case 9: r = de_sqrt_nr(x); break;
+        case 10: r = de_div_rc_ng(x, y, 1.0f / y); break;
         default: r = 0.0f;
     }
     out[k] = r;

@@ -20,6 +20,8 @@ DE_DEV vec3 operator*(vec3 a, vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.
 DE_DEV vec3 operator/(vec3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
 DE_DEV float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DE_DEV float length(vec3 a) { return de_sqrt(dot(a, a)); }
+// |a| for positions (|a|^2 ~ 4e13) and other vectors known to be far from the under/overflow ranges
+DE_DEV float length_nr(vec3 a) { return de_sqrt_nr(dot(a, a)); }
 DE_DEV vec3 normalized(vec3 a) { return a / length(a); }
 DE_DEV vec3 cross(vec3 a, vec3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DE_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
@@ -82,7 +84,7 @@ struct TexF3 {
     int w, h;
 };
 
-DE_DEV float unorm8(uint32_t b) { return DE_DIVC((float)b, 255.0f); }   // == (float)b / 255.0f
+DE_DEV float unorm8(uint32_t b) { return DE_DIVC_NG((float)b, 255.0f); }   // == (float)b / 255.0f, b in 0..255
 
 struct TapCount { uint32_t r8, rgb; };
 
@@ -179,8 +181,9 @@ DE_DEV vec2_ rsi(vec3 pos, vec3 dir, float r) {
 }
 DE_DEV vec2_ sphere_UV_map(vec3 n) {                                                                   // :25-28
     vec2_ o;
-    o.x = (DE_DIVC(de_atan2(n.z, -n.x), (float)M_PI) + 1.0f) / 2.0f;
-    o.y = DE_DIVC(de_asin(n.y), (float)M_PI) + 0.5f;
+    // unguarded: |angle| <= pi; an angle below 2^-100 gives a quotient that the "+ 1" / "+ 0.5" absorbs whatever its last bits
+    o.x = (DE_DIVC_NG(de_atan2(n.z, -n.x), (float)M_PI) + 1.0f) / 2.0f;
+    o.y = DE_DIVC_NG(de_asin(n.y), (float)M_PI) + 0.5f;
     return o;
 }
 DE_DEV float fract_(float x) { return x - de_floor(x); }
@@ -354,11 +357,13 @@ DE_DEV float spectra_extinction_ozone(float wavelength, const float* o3_lut) {  
         ext = (float)(0.0001 * (2.5035422e25 * 0.012588 * 8e-6)) * o3_lut[(int)(wavelength - 390.0f)];
     return ext;
 }
+// Densities are evaluated for 0 <= h <= ~120 km (inside the atmosphere segment), h a multiple of 0.5 m (|pos| ~ 6.4e6):
+// every constant division below has a numerator that is 0 or far above 2^-100, so the unguarded 3-operation form applies.
 DE_DEV float get_ozone_density(float h) {                                                              // :229-247
     float h_km = h * 0.001f;
     float rel = h_km - (float)(25000.0 * 0.001);
     rel = rel * rel;
-    float d = (float)(1.0 - 0.375) * de_exp(DE_DIVC(-rel, 49.0f));
+    float d = (float)(1.0 - 0.375) * de_exp(DE_DIVC_NG(-rel, 49.0f));
     d += 0.375f * de_exp(-rel / 256.0f);
     float t = h_km - 15.0f;
     d += de_max(0.0f, -0.000015f * (t * t * t));
@@ -366,14 +371,22 @@ DE_DEV float get_ozone_density(float h) {                                       
 }
 DE_DEV float get_rayl_density(float h) {                                                               // :249-253
     float t = h + 24239.99f;
-    return DE_DIVC(3.68082f * de_exp(DE_DIVC(-(t * t), 532307548.4168f)), 1.225f);
+    return DE_DIVC_NG(3.68082f * de_exp(DE_DIVC_NG(-(t * t), 532307548.4168f)), 1.225f);
 }
-DE_DEV float get_mie_density(float h) {                                                                // :255-268
-    float dens;
-    if (h > 11500.0f)      { float t = h - 11500.0f; dens = 0.0918f * de_exp(-1.0e-6f * (t * t)); }
-    else if (h > 2400.0f)  { float t = h + 2500.0f;  dens = 0.3000f * de_exp(-2.5e-9f * (t * t)) - 0.092f; }
-    else if (h > 1300.0f)  { float t = h - 1300.0f;  dens = 0.6500f * de_exp(-5.0e-6f * (t * t)) + 0.18899f; }
-    else                   { dens = 1.0f - DE_DIVC(h, 8136.646f); }
+// :255-268.  The reference's four-way branch, with the three exponential branches folded into ONE exp call on
+// per-lane selected (offset, scale, coefficient, addend): a wave whose lanes sit in different altitude bands would
+// otherwise execute all three.  Same operations per lane: 0.0918*e + 0 == 0.0918*e, x - 0.092 == x + (-0.092).
+DE_DEV float get_mie_density(float h) {
+    const bool bA = h > 11500.0f, bB = h > 2400.0f, bC = h > 1300.0f;
+    const float off = bA ? -11500.0f : (bB ? 2500.0f : -1300.0f);
+    const float k = bA ? -1.0e-6f : (bB ? -2.5e-9f : -5.0e-6f);
+    const float coef = bA ? 0.0918f : (bB ? 0.3000f : 0.6500f);
+    const float add = bA ? 0.0f : (bB ? -0.092f : 0.18899f);
+    float t = h + off;
+    float e = de_exp(k * (t * t));
+    float dens = coef * e + add;
+    float lin = 1.0f - DE_DIVC_NG(h, 8136.646f);
+    dens = bC ? dens : lin;
     return dens * (float)1.06;
 }
 DE_DEV vec3 get_density(float h) {                                                                     // :271-274

@@ -41,6 +41,31 @@ DE_DEV float de_div_rc(float x, float c, float rc) {
     return q;
 }
 #define DE_DIVC(x, c) de_div_rc((x), (c), 1.0f / (c))
+// Unguarded forms for call sites whose numerator range is known (stated at each use): x is 0 or 2^-100 <= |x| <= 2^100.
+DE_DEV float de_div_rc_ng(float x, float c, float rc) {
+    float q0 = x * rc;
+    float r = de_fma(-q0, c, x);
+    return de_fma(r, rc, q0);
+}
+#define DE_DIVC_NG(x, c) de_div_rc_ng((x), (c), 1.0f / (c))
+// numerator in [2^-100, 2^100] or +inf (the free-flight distance -log(rand) with rand = 0)
+DE_DEV float de_div_rc_pinf(float x, float c, float rc) {
+    float q = de_div_rc_ng(x, c, rc);
+    return (x == __builtin_inff()) ? x : q;
+}
+
+// sqrt for x = 0 or a normal x in [2^-60, 2^60]: v_sqrt_f32 (<= 1 ulp) corrected to the nearest value with two residual
+// tests — the core of the compiler's IEEE expansion without its denormal scaling and class checks (21 -> 9 operations).
+// tests/test_gpu_parity.py::test_fast_sqrt_is_correctly_rounded compares it with the IEEE result for every significand
+// at both exponent parities.
+DE_DEV float de_sqrt_nr(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    float s_dn = de_u2f(de_f2u(s) - 1u), s_up = de_u2f(de_f2u(s) + 1u);
+    float d_dn = de_fma(-s_dn, s, x), d_up = de_fma(-s_up, s, x);
+    s = (d_dn <= 0.0f) ? s_dn : s;
+    s = (d_up > 0.0f) ? s_up : s;
+    return s;
+}
 
 #define DE_PI 0x1.921fb6p+1f
 #define DE_PIO2 0x1.921fb6p+0f

@@ -124,13 +124,16 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #define DE_V2_CHUNK 512            // work items a wave takes from the device-wide counter per atomic
 #endif
 #define DE_V2_STASH_FIELDS 33
+#ifndef DE_V2_MIN_WAVES
+#define DE_V2_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#endif
 #ifndef DE_V2_PENDING_THRESHOLD
 #define DE_V2_PENDING_THRESHOLD 12   // run the transition pass when at least this many lanes wait for it
 #endif
 
 // MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
 template <bool CLAMP, int MODE>
-__global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
+__global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a) {
     using namespace v2;
     // Persistent waves over WORK ITEMS = single samples.  Item w of the launch is sample (w / 64) % spp of lane-pixel
     // (w & 63) of owned tile a.tiles[w / (64 * spp)].  A wave takes chunks of DE_V2_CHUNK consecutive items from a
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     const float ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
                     const float maxc = ext_w * DE_CLOUDS_DENSITY;
                     const float rmaxc = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
-                    float t_step = de_div_rc(-de_log(rng_next(rng)), maxc, rmaxc);
+                    float t_step = de_div_rc_pinf(-de_log(rng_next(rng)), maxc, rmaxc);
                     C = C + t_step * W;
                     t += t_step;
                     if (MODE) wk.tracking_steps++;
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     if (state == S_NRM3) Q = P - v3(0.0f, 0.0f, e);
                 }
                 if (tap_alive) {
-                    tap_len = length(Q);
+                    tap_len = length_nr(Q);                        // positions: |Q|^2 ~ 4e13
                     tap_do = !cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER);
                     if (tap_do) {
                         const vec3 n = Q / tap_len;
@@ -260,8 +263,10 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
             if (gasL) {
                 const vec3 W = (state == S_DT_G) ? D : LD;
                 // x / maxr: 3 operations where the device-side proof passed for this wavelength (LambdaNode::fast_div), else the divide
-                auto gas_div = [&](float x) -> float { return (rmaxr != 0.0f) ? de_div_rc(x, maxr, rmaxr) : x / maxr; };
-                float t_step = gas_div(-de_log(rng_next(rng)));
+                // numerators: sums of extinction x density, >= 1e-20 inside the atmosphere (Rayleigh density >= 2e-15 up to 110 km)
+                auto gas_div = [&](float x) -> float { return (rmaxr != 0.0f) ? de_div_rc_ng(x, maxr, rmaxr) : x / maxr; };
+                const float neg_log = -de_log(rng_next(rng));
+                float t_step = (rmaxr != 0.0f) ? de_div_rc_pinf(neg_log, maxr, rmaxr) : neg_log / maxr;
                 C = C + t_step * W;
                 t += t_step;
                 if (MODE) wk.tracking_steps++;
@@ -269,7 +274,7 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                     if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
                     else { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
                 } else {
-                    vec3 dens = get_density(de_sqrt((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
+                    vec3 dens = get_density(de_sqrt_nr((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
                     vec3 es = v3(ext_r, ext_m, ext_o) * dens;
                     float sum = (es.x + es.y) + es.z;
                     if (state == S_DT_G) {
@@ -316,19 +321,19 @@ __global__ void __launch_bounds__(256) render_kernel_v2(RenderArgs a) {
                         // get_clouds_density, pathtracer.py:48-65
                         float density = 0.0f;
                         if (tap_do) {
-                            float h = DE_DIVC(len - DE_CLOUDS_LOWER, DE_CLOUDS_THICKNESS);
+                            float h = DE_DIVC_NG(len - DE_CLOUDS_LOWER, DE_CLOUDS_THICKNESS);   // a multiple of 2^-1 in (0, 6000)
                             const float split = 0.2f;
                             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
                         }
                         float es = ext_w * (density * DE_CLOUDS_DENSITY);
                         if (state == S_DT_C) {
                             float rand = rng_next(rng);
-                            if (rand < de_div_rc(es, maxc, rmaxc)) {
+                            if (rand < de_div_rc_ng(es, maxc, rmaxc)) {                 // es is 0 or >= 2e-4
                                 rmo_event |= ((rng_next(rng) < 0.99f) ? EV_SCATTER : EV_ABSORB) << 4;   // cloud event in bits 4-5
                                 state = S_AFTER_DT_C;
                             }
                         } else {
-                            trn *= 1.0f - de_div_rc(es, maxc, rmaxc);
+                            trn *= 1.0f - de_div_rc_ng(es, maxc, rmaxc);
                             if (trn < 1e-5f) state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
                         }
                     } else {

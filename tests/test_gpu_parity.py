@@ -239,3 +239,27 @@ def test_kernel_variants_agree(Renderer, preset):
     assert (out[1][0].view(np.uint32) == out[2][0].view(np.uint32)).all()
     assert out[1][1] == out[2][1]
     assert (out[1][2].view(np.uint32) == out[2][2].view(np.uint32)).all()
+
+
+def test_fast_sqrt_is_correctly_rounded(Renderer):
+    """de_sqrt_nr (v_sqrt_f32 + residual correction) == IEEE sqrt for EVERY significand at both exponent parities."""
+    r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
+    m = np.arange(1 << 23, dtype=np.uint32)
+    for expo in (127, 128, 172, 173, 97):          # x in [1,2), [2,4), ~4e13 (|pos|^2), ~1e-9
+        x = ((np.uint32(expo) << np.uint32(23)) | m).view(np.float32)
+        got = r.debug_math(9, x)
+        want = np.sqrt(x.astype(np.float64)).astype(np.float32)     # correctly rounded: f64 sqrt of an f32 rounds once more, exact for 24-bit inputs
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), expo
+    assert r.debug_math(9, np.array([0.0], np.float32))[0] == 0.0
+
+
+def test_three_operation_division_by_literals(Renderer):
+    """de_div_rc_ng(x, c) == x / c for every significand of x, for the literal divisors used by the kernels
+    (the device-side twin of tools/verify_exact_div.c)."""
+    r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
+    m = np.arange(1 << 23, dtype=np.uint32)
+    x = ((np.uint32(127) << np.uint32(23)) | m).view(np.float32)
+    for c in (255.0, np.float32(np.pi), 49.0, np.float32(532307548.4168), np.float32(1.225), np.float32(8136.646), 6000.0,
+              np.float32(0.1) * np.float32(0.029), np.float32(0.02) * np.float32(0.029)):
+        cc = np.full_like(x, np.float32(c))
+        assert (r.debug_math(10, x, cc).view(np.uint32) == r.debug_math(7, x, cc).view(np.uint32)).all(), c
