@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
         // while it is in flight, and the texel is consumed in the second half below.
         uint32_t tap_q = 0;
         float tap_fx = 0.0f, tap_fy = 0.0f, tap_len = 0.0f;
-        bool tap_alive = false, tap_do = false;
+        bool tap_alive = false, tap_do = false, tap_escaped = false;
         if (m_tap != 0ull) {
             if (tapL) {
                 const bool cloud = is_cloud_tap(state);
@@ -241,6 +241,18 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 if (tap_alive) {
                     tap_len = length_nr(Q);                        // positions: |Q|^2 ~ 4e13
                     tap_do = !cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER);
+                    // Escaped ray (generalises SURVEY Q2).  If the rest of the ray stays more than 8 km above every possible
+                    // terrain height (its perigee, or its current point once it moves outward), every further SDF value is
+                    // > 8 km > 1e-4 * max_ray_dist (6371 m): the `abs(dist) < ray_dist*1e-4` test can never fire again, each
+                    // step advances by at least its height, and the trace leaves through ray_dist > max_ray_dist after at most
+                    // 127 more steps (worst case: inward tangent ray over maximal terrain) — inside the 250-step budget while
+                    // cnt <= 100.  The result is -1 whatever the steps in between: skip them.
+                    if (state <= S_ST_S && cnt <= 100) {
+                        const float b = dot(Q, W);
+                        const float K = DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f;
+                        const float peri2 = (b < 0.0f) ? (tap_len * tap_len - b * b) : tap_len * tap_len;
+                        if (peri2 > K * K) { tap_escaped = true; tap_do = false; }
+                    }
                     if (tap_do) {
                         const vec3 n = Q / tap_len;
                         if (MODE) wk.taps_r8++;
@@ -338,7 +350,10 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         }
                     } else {
                         float sdf = len - DE_PLANET_R - fc.land_height_scale * tex;
-                        if (state <= S_ST_S) {
+                        if (state <= S_ST_S && tap_escaped) {
+                            t = MAX_RAY_DIST;                              // "ray_dist < max_ray_dist" fails -> -1
+                            state = (state == S_ST_P) ? S_AFTER_ST_P : S_AFTER_ST_S;
+                        } else if (state <= S_ST_S) {
                             t += sdf;
                             cnt++;
                             if (MODE) wk.sphere_steps++;
