@@ -90,18 +90,22 @@ def main():
     from digital_earth_amd.renderer import Renderer
     from digital_earth_amd import parallel
 
-    torch.cuda.set_device(local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev          # one rank per GPU on the driver's node; modulo only matters for the 1-GPU dry run
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL on ROCm.  DE_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a single-GPU box.
+        backend = os.environ.get("DE_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", device_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
     W, H, spp = args.width, args.height, args.spp
-    r = Renderer((W, H), (0, 1, 0), device=local_rank, texture_source="synthetic", texture_quality=args.tex_quality,
+    r = Renderer((W, H), (0, 1, 0), device=device_index, texture_source="synthetic", texture_quality=args.tex_quality,
                  cloud_heavy=args.cloud_heavy, seed=0)
     if args.preset:
         apply_preset(r, args.preset)
     r.copy_textures()
-    frame = parallel.DistributedFrame(r, rank, world, local_rank)
+    frame = parallel.DistributedFrame(r, rank, world, device_index)
 
     def barrier():
         torch.cuda.synchronize()

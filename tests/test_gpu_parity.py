@@ -266,3 +266,61 @@ def test_three_operation_division_by_literals(Renderer):
               np.float32(0.1) * np.float32(0.029), np.float32(0.02) * np.float32(0.029)):
         cc = np.full_like(x, np.float32(c))
         assert (r.debug_math(10, x, cc).view(np.uint32) == r.debug_math(7, x, cc).view(np.uint32)).all(), c
+
+
+def test_real_texture_files_and_orientation(Renderer, lut_arrays, tmp_path):
+    """`texture_source="files"`: PNG/JPG maps named as lib/textures.py expects, read with Taichi's imread orientation
+    ([x][y], y up: image row 0 is the NORTH edge = last texel row)."""
+    from PIL import Image
+    from digital_earth_amd import textures as T
+    rng = np.random.default_rng(5)
+    table = T.texture_table(0)
+    expect = {}
+    for slot, (name, _) in table.items():
+        ch = T.SLOT_CHANNELS[slot]
+        img = rng.integers(0, 256, size=(32, 64, 3), dtype=np.uint8)        # image rows top-down
+        if ch == 1:
+            img[..., 1] = img[..., 0]; img[..., 2] = img[..., 0]
+        if name.endswith(".jpg"):
+            name_out = name                                                    # lossy: only check it loads
+        Image.fromarray(img).save(str(tmp_path / name))
+        expect[slot] = img[::-1, :, :ch]
+    with pytest.raises(FileNotFoundError):
+        Renderer((64, 32), (0, 1, 0), texture_source="files", texture_dir=str(tmp_path / "missing"), texture_quality=0)
+    r = Renderer((64, 32), (0, 1, 0), texture_source="files", texture_dir=str(tmp_path), texture_quality=0)
+    r.set_fov(0.45)
+    r.copy_textures()
+    texels = [r.download_texture(s) for s in range(7)]
+    for slot in range(7):
+        if not table[slot][0].endswith(".jpg"):
+            assert (texels[slot] == expect[slot]).all(), slot
+    o = make_oracle(64, 32, lut_arrays, texels, r._params)
+    r.accumulate(2); o.accumulate(2, 0)
+    assert (r.fetch_hdr().view(np.uint32) == o.fetch_hdr().view(np.uint32)).all()
+
+
+def test_resume_from_uploaded_accumulation(Renderer):
+    """Progressive state = (HDR sums, sample count): a render resumed from a saved state continues bit-identically."""
+    kw = dict(texture_source="synthetic", texture_size=(1024, 512))
+    a = Renderer((64, 64), (0, 1, 0), **kw); a.set_fov(0.4)
+    a.accumulate(5)
+    full = a.fetch_hdr()
+    b = Renderer((64, 64), (0, 1, 0), **kw); b.set_fov(0.4)
+    b.accumulate(2)
+    saved, spp = b.fetch_hdr(), b.current_spp
+    c = Renderer((64, 64), (0, 1, 0), **kw); c.set_fov(0.4)
+    c.upload_hdr(saved, spp)
+    c.accumulate(3)
+    assert c.current_spp == 5
+    assert (c.fetch_hdr().view(np.uint32) == full.view(np.uint32)).all()
+
+
+def test_headless_earth_viewer(tmp_path):
+    from digital_earth_amd.earth_viewer import EarthViewer
+    v = EarthViewer(config="config - florida.txt", screen_res=(128, 72), texture_source="synthetic", texture_size=(1024, 512))
+    img = v.render(spp=4)
+    assert img.shape == (128, 72, 3) and img.dtype == np.float32 and 0.0 <= img.min() and img.max() <= 1.0 and img.mean() > 0.01
+    out = tmp_path / "florida.png"
+    v.save(str(out))
+    assert out.stat().st_size > 1000
+    assert v.renderer.current_spp == 4 and v.renderer.crf_names[0] == "Neutral.rf"

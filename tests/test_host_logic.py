@@ -49,3 +49,17 @@ def test_tile_partition_masks():
     # ownership rule used by the kernel: 8x8 tile (tx, ty) -> (tx + ty) % world
     m = parallel.owned_pixel_mask(64, 32, 1, 4)
     assert m[8, 0] and not m[0, 0] and m[0, 8] and m[7 + 8 * 5, 7]
+
+
+def test_image_orientation_matches_taichi_imread(tmp_path):
+    """ti.tools.imread gives [x][y] with y up (renderer.py:63-93): texel row 0 must be the image's bottom row (v = 0 = south)."""
+    from PIL import Image
+    from digital_earth_amd import textures as T
+    img = np.zeros((4, 6, 3), np.uint8)
+    img[0, :, 0] = 200          # top row of the picture = north
+    img[3, :, 0] = 10           # bottom row = south
+    p = tmp_path / "m.png"
+    Image.fromarray(img).save(str(p))
+    t = T.load_image_texels(str(p), 1)
+    assert t.shape == (4, 6, 1) and (t[0, :, 0] == 10).all() and (t[3, :, 0] == 200).all()
+    assert T.load_image_texels(str(p), 3).shape == (4, 6, 3)
