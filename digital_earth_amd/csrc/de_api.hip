@@ -418,6 +418,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.spp_begin = c->current_spp; a.spp_count = spp;
+    a.spp_magic = ((1ull << 40) / (unsigned long long)(spp > 0 ? spp : 1)) + 1ull;
     {   // per-sample contribution buffer of render_kernel_v2 (8 B per sample of this rank's tiles; grows on demand)
         const size_t need = (size_t)a.n_tiles * 64u * (size_t)(spp > 0 ? spp : 1);
         if (need >= (size_t)1 << 32) return fail(DE_ERR_INVALID, "spp too large for one launch: split the call (n_tiles*64*spp must be < 2^32)");
@@ -561,6 +562,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     a.spp_begin = sample_index; a.spp_count = 1;
+    a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
     launch_render<2>(c, a);
     HIP_TRY(hipGetLastError());

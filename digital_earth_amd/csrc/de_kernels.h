@@ -61,6 +61,7 @@ struct RenderArgs {
     unsigned long long* counters; // [8] when counting
     float* debug_out;             // [H][W][4] when tracing single samples
     uint32_t* work_counter;       // v2: device-wide work-item counter (zeroed before each launch)
+    unsigned long long spp_magic; // v2: floor(2^40 / spp_count) + 1
     uint2* contrib;               // v2: per-sample (radiance bits, wavelength node), index = work item
     int pend_thr;                 // v2: lanes that must wait before the transition pass runs
     int heavy_thr;                // v2: stashed paths of one kind that trigger a batch (env DE_V2_A)

@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
     // stashed path waiting for the same transition, those lanes swap the stashed path in, run the transition
     // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
     // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
+    __shared__ float s_node_val[256];     // spectrum_sample's bisection values: 8 dependent reads per new path, from LDS
+    s_node_val[threadIdx.x] = a.node_val[threadIdx.x];
+    __syncthreads();
     __shared__ uint32_t s_stash[4][DE_V2_STASH_FIELDS][64];
     uint32_t* const slot = &s_stash[threadIdx.x >> 6][0][lane];
     int stash = 0;                        // 0 empty; 1/2/3 waiting for S_SC_FINISH / S_SURF_SETUP / S_SURF_FINISH; 4 ready to resume
@@ -641,16 +644,18 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 if (!got) {
                     state = S_DONE;
                 } else {
-                    const uint32_t tile = a.tiles[w / items_per_tile];
-                    const uint32_t r = w % items_per_tile;
-                    const int s_idx = (int)(r >> 6);
-                    const int sub = (int)(r & 63u);
+                    // (w >> 6) / spp by multiplication (a.spp_magic = floor(2^40 / spp) + 1; exact while (w >> 6) * spp < 2^40)
+                    const uint32_t wq = w >> 6;
+                    const uint32_t tile_k = (uint32_t)(((unsigned long long)wq * a.spp_magic) >> 40);
+                    const uint32_t tile = a.tiles[tile_k];
+                    const int s_idx = (int)(wq - tile_k * (uint32_t)a.spp_count);
+                    const int sub = (int)(w & 63u);
                     const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
                     const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
                     const uint32_t pixel = (uint32_t)(v * a.W + u);
                     rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
                     node = 0;
-                    if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
+                    if (!a.fixed_wavelength) node = v2::spectrum_node(s_node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];
                     ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; maxr = L.max_ext_rmo;
                     rmaxr = (L.fast_div != 0.0f) ? L.inv_max_ext_rmo : 0.0f;
