@@ -74,6 +74,28 @@ DE_DEV void intersect_cloud_limits(vec3 ray_pos, vec3 ray_dir, float land_isecti
     }
     *t_start_out = t_start; *t_max_out = t_max;
 }
+// pathtracer.py:145-168 up to (not including) the `if land_isection > 0.0: t_max = -1.0` of the below-cloud branch:
+// everything that depends on the ray alone, computed when the ray is set up.  `below` tells the caller to apply that line.
+DE_DEV void cloud_limits_of_ray(vec3 ray_pos, vec3 ray_dir, float* t_start_out, float* t_max_out, int* below_out) {
+    float t_start = 0.0f, t_max = 0.0f;
+    int below = 0;
+    float elevation = length(ray_pos);
+    vec2_ lower = rsi(ray_pos, ray_dir, DE_CLOUDS_LOWER);
+    vec2_ upper = rsi(ray_pos, ray_dir, DE_CLOUDS_UPPER);
+    if (elevation >= DE_CLOUDS_UPPER) {
+        t_start = de_max(0.0f, upper.x);
+        t_max = (lower.y >= 0.0f) ? lower.x : upper.y;
+        if (upper.y < 0.0f) t_max = -1.0f;
+    } else if (elevation >= DE_CLOUDS_LOWER) {
+        t_start = 0.0f;
+        t_max = (lower.y >= 0.0f) ? lower.x : upper.y;
+    } else {
+        t_start = lower.y;
+        t_max = upper.y;
+        below = 1;
+    }
+    *t_start_out = t_start; *t_max_out = t_max; *below_out = below;
+}
 // pathtracer.py:235-247
 DE_DEV float evaluate_phase(const FrameConsts& fc, vec3 ray_dir, vec3 light_dir, int id, bool reduce_peak) {
     float phase = 0.0f;
@@ -123,7 +145,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #ifndef DE_V2_CHUNK
 #define DE_V2_CHUNK 512            // work items a wave takes from the device-wide counter per atomic
 #endif
-#define DE_V2_STASH_FIELDS 33
+#define DE_V2_STASH_FIELDS 36
 #ifndef DE_V2_MIN_WAVES
 #define DE_V2_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -165,6 +187,8 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
     float isect = 0.0f, rmo_t = 0.0f;
     int rmo_event = 0, ev_id = 0;         // ev_id: interaction id of the resolved event
     float li = -1.0f;                     // land_isection argument of the light-sample transmittance
+    float c_ts = 0.0f, c_tm = 0.0f;       // cloud-shell segment of the ray being traced (cloud_limits_of_ray)
+    int c_below = 0;
     float d0 = 0.0f, alb = 0.0f, ocean = 0.0f, bathy = 0.0f;
     float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f, rmaxr = 0.0f;   // rmaxr = 1/maxr when the 3-op division is proven exact, else 0
     int state = S_NEW;
@@ -190,10 +214,45 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
       DE_XF(8, LD.z) DE_XF(9, N.x) DE_XF(10, N.y) DE_XF(11, N.z) DE_XF(12, thr) DE_XF(13, Ls) DE_XF(14, trg) DE_XF(15, trn) \
       DE_XF(16, alb) DE_XF(17, ocean) DE_XF(18, bathy) DE_XF(19, li) DE_XF(20, atm_x) DE_XF(21, atm_y) DE_XF(22, t)       \
       DE_XF(23, sc) DE_XF(24, rng.s0) DE_XF(25, rng.s1) DE_XF(26, rng.draws) DE_XF(27, node) DE_XF(28, w) DE_XF(29, ev_id) \
-      DE_XF(30, state) DE_XF(31, path_vertices) DE_XF(32, cnt) }
+      DE_XF(30, state) DE_XF(31, path_vertices) DE_XF(32, cnt) DE_XF(33, c_ts) DE_XF(34, c_tm) DE_XF(35, c_below) }
 #define DE_RELOAD_NODE()                                                                                                \
     { const LambdaNode& Ln_ = a.nodes[node]; ext_r = Ln_.ext_r; ext_m = Ln_.ext_m; ext_o = Ln_.ext_o; maxr = Ln_.max_ext_rmo; \
       rmaxr = (Ln_.fast_div != 0.0f) ? Ln_.inv_max_ext_rmo : 0.0f; }
+
+    // ---- loop-to-loop glue, executed in place by the lane that finishes a loop (no wait for the transition pass)
+    // enter the cloud-shell segment of the current ray: kind 0 = delta tracking of the path ray, 1 / 2 = light sample of a volume / surface vertex
+    auto enter_cloud = [&](int kind) {
+        const vec3 W = (kind == 0) ? D : LD;
+        const float li_arg = (kind == 0) ? isect : li;
+        const float t_start = c_ts;
+        const float t_max = (c_below && li_arg > 0.0f) ? -1.0f : c_tm;              // pathtracer.py:166
+        bool run = true;
+        if (kind == 0) run = (rmo_event == EV_NULL) || (rmo_t > t_start);            // pathtracer.py:195
+        t = t_start; tmax = t_max;
+        C = P + t * W;
+        trn = 1.0f;
+        const bool enter = run && (t_start < t_max);
+        if (kind == 0) state = enter ? S_DT_C : S_AFTER_DT_C;
+        else if (kind == 1) state = enter ? S_RT_C_V : S_SC_FINISH;
+        else state = enter ? S_RT_C_S : S_SURF_FINISH;
+    };
+    // after a sphere trace (pathtracer.py:46): its result, then the gas segment of the same ray (pathtracer.py:180-184, 219-225)
+    auto after_sphere_trace = [&](bool primary) {
+        const float hit = (t < MAX_RAY_DIST) ? t : -1.0f;
+        float land_isection;
+        if (primary) { isect = hit; land_isection = hit; }
+        else { li = (hit < 0.0f) ? -1.0f : 0.0f; land_isection = li; }
+        const float t_start = de_max(0.0f, atm_x);
+        float t_max = (land_isection >= 0.0f) ? land_isection : atm_y;
+        if (atm_y < 0.0f) t_max = -1.0f;
+        const vec3 W = primary ? D : LD;
+        t = t_start; tmax = t_max;
+        C = P + t * W;
+        trn = 1.0f;
+        if (t_start < t_max) state = primary ? S_DT_G : S_RT_G_S;
+        else if (primary) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; enter_cloud(0); }
+        else { trg = 1.0f; enter_cloud(2); }
+    };
 
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = (MODE == 1) ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t st_batches = 0, st_batch_lanes = 0, st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
@@ -286,8 +345,8 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 t += t_step;
                 if (MODE) wk.tracking_steps++;
                 if (t >= tmax) {
-                    if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
-                    else { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                    if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; enter_cloud(0); }
+                    else { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
                 } else {
                     vec3 dens = get_density(de_sqrt_nr((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
                     vec3 es = v3(ext_r, ext_m, ext_o) * dens;
@@ -310,11 +369,11 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                             rmo_event = (rng_next(rng) < albedo) ? EV_SCATTER : EV_ABSORB;
                             rmo_t = t;
                             ev_id = id;
-                            state = S_CLOUD_SETUP_DT;
+                            enter_cloud(0);
                         }
                     } else {
                         trn *= 1.0f - gas_div(sum);
-                        if (trn < 1e-5f) { trg = trn; state = (state == S_RT_G_V) ? S_CLOUD_SETUP_V : S_CLOUD_SETUP_S; }
+                        if (trn < 1e-5f) { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
                     }
                 }
             }
@@ -355,12 +414,12 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         float sdf = len - DE_PLANET_R - fc.land_height_scale * tex;
                         if (state <= S_ST_S && tap_escaped) {
                             t = MAX_RAY_DIST;                              // "ray_dist < max_ray_dist" fails -> -1
-                            state = (state == S_ST_P) ? S_AFTER_ST_P : S_AFTER_ST_S;
+                            after_sphere_trace(state == S_ST_P);
                         } else if (state <= S_ST_S) {
                             t += sdf;
                             cnt++;
                             if (MODE) wk.sphere_steps++;
-                            if (t > MAX_RAY_DIST || de_abs(sdf) < t * 0.0001f || cnt >= 250) state = (state == S_ST_P) ? S_AFTER_ST_P : S_AFTER_ST_S;
+                            if (t > MAX_RAY_DIST || de_abs(sdf) < t * 0.0001f || cnt >= 250) after_sphere_trace(state == S_ST_P);
                         } else {
                             if (state == S_NRM0) d0 = sdf;
                             else if (state == S_NRM1) N.x = d0 - sdf;
@@ -391,45 +450,6 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
         if (MODE == 1) { st_passes++; st_pend_lanes += n_pend; }
 
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
-        // ---- after a sphere trace (pathtracer.py:46): result, then the gas segment of the same ray
-        if (__ballot(state == S_AFTER_ST_P || state == S_AFTER_ST_S) != 0ull) {
-            if (state == S_AFTER_ST_P || state == S_AFTER_ST_S) {
-                const float hit = (t < MAX_RAY_DIST) ? t : -1.0f;
-                float land_isection;
-                if (state == S_AFTER_ST_P) { isect = hit; land_isection = hit; }
-                else { li = (hit < 0.0f) ? -1.0f : 0.0f; land_isection = li; }
-                // sample_interaction / sample_transmittance head (pathtracer.py:180-184, 219-225); rsi(atmosphere) is the
-                // value intersect_land already computed for this ray
-                float t_start = de_max(0.0f, atm_x);
-                float t_max = (land_isection >= 0.0f) ? land_isection : atm_y;
-                if (atm_y < 0.0f) t_max = -1.0f;
-                const vec3 W = (state == S_AFTER_ST_P) ? D : LD;
-                t = t_start; tmax = t_max;
-                C = P + t * W;
-                trn = 1.0f;
-                if (t_start < t_max) state = (state == S_AFTER_ST_P) ? S_DT_G : S_RT_G_S;
-                else if (state == S_AFTER_ST_P) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; state = S_CLOUD_SETUP_DT; }
-                else { trg = 1.0f; state = S_CLOUD_SETUP_S; }
-            }
-        }
-        // ---- cloud-shell segment (pathtracer.py:189,195-198 / 229-231)
-        if (__ballot(state >= S_CLOUD_SETUP_DT && state <= S_CLOUD_SETUP_S) != 0ull) {
-            if (state >= S_CLOUD_SETUP_DT && state <= S_CLOUD_SETUP_S) {
-                const bool dt = (state == S_CLOUD_SETUP_DT);
-                const vec3 W = dt ? D : LD;
-                float t_start, t_max;
-                intersect_cloud_limits(P, W, dt ? isect : li, &t_start, &t_max);
-                bool run = true;
-                if (dt) run = (rmo_event == EV_NULL) || (rmo_t > t_start);
-                t = t_start; tmax = t_max;
-                C = P + t * W;
-                trn = 1.0f;
-                const bool enter = run && (t_start < t_max);
-                if (dt) state = enter ? S_DT_C : S_AFTER_DT_C;
-                else if (state == S_CLOUD_SETUP_V) state = enter ? S_RT_C_V : S_SC_FINISH;
-                else state = enter ? S_RT_C_S : S_SURF_FINISH;
-            }
-        }
         // ---- event resolution, light sample, branch (pathtracer.py:200-205, 369-375, 404, 441-444)
         if (__ballot(state == S_AFTER_DT_C) != 0ull) {
             if (state == S_AFTER_DT_C) {
@@ -455,6 +475,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                     } else {
                         li = -1.0f;
                         vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
+                        cloud_limits_of_ray(P, LD, &c_ts, &c_tm, &c_below);
                         float t_start = de_max(0.0f, atmos.x);
                         float t_max = atmos.y;            // land_isection = -1
                         if (atmos.y < 0.0f) t_max = -1.0f;
@@ -462,7 +483,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         C = P + t * LD;
                         trn = 1.0f;
                         if (t_start < t_max) state = S_RT_G_V;
-                        else { trg = 1.0f; state = S_CLOUD_SETUP_V; }
+                        else { trg = 1.0f; enter_cloud(1); }
                     }
                 } else if (isect > 0.0f) {
                     P = P + D * isect;                    // land_pos
@@ -571,6 +592,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         // intersect_land(offset_pos, light_dir) head
                         vec2_ atmos = rsi(P, LD, DE_ATMOS_UPPER);
                         atm_x = atmos.x; atm_y = atmos.y;
+                        cloud_limits_of_ray(P, LD, &c_ts, &c_tm, &c_below);
                         t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
                         cnt = 0;
                         state = S_ST_S;
@@ -674,6 +696,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 if (MODE) { wk.vertices++; path_vertices++; }
                 vec2_ atmos = rsi(P, D, DE_ATMOS_UPPER);
                 atm_x = atmos.x; atm_y = atmos.y;
+                cloud_limits_of_ray(P, D, &c_ts, &c_tm, &c_below);
                 t = (atmos.x > 0.0f) ? atmos.x : 0.0f;
                 cnt = 0;
                 rmo_event = 0;
