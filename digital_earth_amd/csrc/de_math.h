@@ -185,7 +185,7 @@ DE_DEV float de_asin(float x) {
     if (ax > 1.0f) ax = 1.0f;
     bool big = ax > 0.5f;
     float s = big ? (1.0f - ax) * 0.5f : ax * ax;
-    float t = big ? de_sqrt(s) : ax;
+    float t = big ? de_sqrt_nr(s) : ax;           // s is 0 or in [2^-25, 1/4]: the short correctly-rounded sqrt applies
     float p = 0x1.3513acp-5f;
     p = de_fma(p, s, 0x1.d3dfe8p-7f);
     p = de_fma(p, s, 0x1.04f064p-5f);

@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
     uint32_t w = 0;                       // this lane's current item
     const FrameConsts& fc = *a.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+    const bool same_dims = (a.clouds.w == a.topo.w) && (a.clouds.h == a.topo.h);
 
     Work2 wk = {0, 0, 0, 0, 0, 0};
     uint32_t n_samples = 0, path_vertices = 0;
@@ -269,23 +270,36 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
         }
 
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
-        // ============================================================ TAP class, first half: position, UV, issue the tap
-        // The map tap is the long-latency operation of a trip (L2 / HBM).  It is issued here, the GAS class runs
-        // while it is in flight, and the texel is consumed in the second half below.
+        // ============================================================ first half: advance, position, UV, issue the tap
+        // Shared by the TAP class and (on the trips the GAS class runs) the GAS class: a tracking step of either kind starts
+        // with the same free-flight draw, division by its majorant, advance and |position|.  The map tap — the long-latency
+        // operation of a trip (L2 / HBM) — is issued here; the gas densities are evaluated while it is in flight and the
+        // texel is consumed in the second half below.
         uint32_t tap_q = 0;
         float tap_fx = 0.0f, tap_fy = 0.0f, tap_len = 0.0f;
         bool tap_alive = false, tap_do = false, tap_escaped = false;
-        if (m_tap != 0ull) {
-            if (tapL) {
+        // the GAS class runs when enough lanes wait in it (a.gas_thr) or the TAP class is short of lanes
+        const bool run_gas = (m_gas != 0ull) && (__popcll(m_gas) >= a.gas_thr || __popcll(m_tap) < 24);
+        const bool gasR = gasL && run_gas;
+        // x / maxr takes 3 operations where the device-side proof passed for the lane's wavelength (rmaxr != 0);
+        // otherwise (never with the shipped LUTs) the wave takes the branch with the real divide
+        const bool any_slow_div = run_gas && (__ballot(gasR && rmaxr == 0.0f) != 0ull);
+        if (m_tap != 0ull || run_gas) {
+            if (tapL || gasR) {
                 const bool cloud = is_cloud_tap(state);
-                const vec3 W = (state == S_ST_P || state == S_DT_C) ? D : LD;
+                const bool track = cloud || gasR;
+                const vec3 W = (state == S_ST_P || state == S_DT_C || state == S_DT_G) ? D : LD;
                 vec3 Q;
                 tap_alive = true;
-                if (cloud) {
-                    const float ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
-                    const float maxc = ext_w * DE_CLOUDS_DENSITY;
-                    const float rmaxc = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
-                    float t_step = de_div_rc_pinf(-de_log(rng_next(rng)), maxc, rmaxc);
+                if (track) {
+                    float maxv, rmaxv;
+                    if (cloud) {
+                        maxv = ((sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT) * DE_CLOUDS_DENSITY;
+                        rmaxv = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
+                    } else { maxv = maxr; rmaxv = rmaxr; }
+                    const float neg_log = -de_log(rng_next(rng));
+                    float t_step = de_div_rc_pinf(neg_log, maxv, rmaxv);
+                    if (any_slow_div) { if (rmaxv == 0.0f) t_step = neg_log / maxv; }
                     C = C + t_step * W;
                     t += t_step;
                     if (MODE) wk.tracking_steps++;
@@ -302,7 +316,7 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 }
                 if (tap_alive) {
                     tap_len = length_nr(Q);                        // positions: |Q|^2 ~ 4e13
-                    tap_do = !cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER);
+                    tap_do = tapL && (!cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER));
                     // Escaped ray (generalises SURVEY Q2).  If the rest of the ray stays more than 8 km above every possible
                     // terrain height (its perigee, or its current point once it moves outward), every further SDF value is
                     // > 8 km > 1e-4 * max_ray_dist (6371 m): the `abs(dist) < ray_dist*1e-4` test can never fire again, each
@@ -318,11 +332,13 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                     if (tap_do) {
                         const vec3 n = Q / tap_len;
                         if (MODE) wk.taps_r8++;
-                        TexR8 T;   // per-lane map select (two maps only in this class)
+                        TexR8 T = a.topo;   // per-lane map select (two maps only in this class)
                         T.data = cloud ? a.clouds.data : a.topo.data;
-                        T.w = cloud ? a.clouds.w : a.topo.w; T.h = cloud ? a.clouds.h : a.topo.h;
-                        T.tiles_x = cloud ? a.clouds.tiles_x : a.topo.tiles_x;
-                        T.wf = cloud ? a.clouds.wf : a.topo.wf; T.hf = cloud ? a.clouds.hf : a.topo.hf;
+                        if (!same_dims) {   // wave-uniform: the reference's tiers give both maps one size (lib/textures.py:65-79)
+                            T.w = cloud ? a.clouds.w : a.topo.w; T.h = cloud ? a.clouds.h : a.topo.h;
+                            T.tiles_x = cloud ? a.clouds.tiles_x : a.topo.tiles_x;
+                            T.wf = cloud ? a.clouds.wf : a.topo.wf; T.hf = cloud ? a.clouds.hf : a.topo.hf;
+                        }
                         vec2_ uv = sphere_UV_map(n);
                         tap_q = tap_r8_issue<CLAMP>(T, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &tap_fx, &tap_fy);
                     }
@@ -331,24 +347,20 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
         }
 
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[1] += now_ - tlast; tlast = now_; }
-        // ============================================================ GAS class
-        // runs when enough lanes wait in it (a.gas_thr) or the TAP class is short of lanes
-        if (m_gas != 0ull && (__popcll(m_gas) >= a.gas_thr || __popcll(m_tap) < 24)) {
-            if (gasL) {
-                const vec3 W = (state == S_DT_G) ? D : LD;
-                // x / maxr: 3 operations where the device-side proof passed for this wavelength (LambdaNode::fast_div), else the divide
+        // ============================================================ GAS class: densities and collision / transmittance
+        if (run_gas) {
+            if (gasR) {
                 // numerators: sums of extinction x density, >= 1e-20 inside the atmosphere (Rayleigh density >= 2e-15 up to 110 km)
-                auto gas_div = [&](float x) -> float { return (rmaxr != 0.0f) ? de_div_rc_ng(x, maxr, rmaxr) : x / maxr; };
-                const float neg_log = -de_log(rng_next(rng));
-                float t_step = (rmaxr != 0.0f) ? de_div_rc_pinf(neg_log, maxr, rmaxr) : neg_log / maxr;
-                C = C + t_step * W;
-                t += t_step;
-                if (MODE) wk.tracking_steps++;
-                if (t >= tmax) {
+                auto gas_div = [&](float x) -> float {
+                    float q = de_div_rc_ng(x, maxr, rmaxr);
+                    if (any_slow_div) { if (rmaxr == 0.0f) q = x / maxr; }
+                    return q;
+                };
+                if (!tap_alive) {                                  // t >= t_max: the segment ends without an event
                     if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; enter_cloud(0); }
                     else { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
                 } else {
-                    vec3 dens = get_density(de_sqrt_nr((C.x * C.x + C.y * C.y) + C.z * C.z) - DE_PLANET_R);
+                    vec3 dens = get_density(tap_len - DE_PLANET_R);   // volume.get_density(volume.get_elevation(pos))
                     vec3 es = v3(ext_r, ext_m, ext_o) * dens;
                     float sum = (es.x + es.y) + es.z;
                     if (state == S_DT_G) {

@@ -248,7 +248,7 @@ def test_fast_sqrt_is_correctly_rounded(Renderer):
     """de_sqrt_nr (v_sqrt_f32 + residual correction) == IEEE sqrt for EVERY significand at both exponent parities."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
     m = np.arange(1 << 23, dtype=np.uint32)
-    for expo in (127, 128, 172, 173, 97):          # x in [1,2), [2,4), ~4e13 (|pos|^2), ~1e-9
+    for expo in (127, 128, 172, 173, 97, 110, 111):   # x in [1,2), [2,4), ~4e13 (|pos|^2), ~1e-9, asin's (1-|x|)/2 range
         x = ((np.uint32(expo) << np.uint32(23)) | m).view(np.float32)
         got = r.debug_math(9, x)
         want = np.sqrt(x.astype(np.float64)).astype(np.float32)     # correctly rounded: f64 sqrt of an f32 rounds once more, exact for 24-bit inputs
