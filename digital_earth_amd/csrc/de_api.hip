@@ -223,6 +223,8 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
     a->pend_thr = 16; a->heavy_thr = 12; a->tune_b = 40; a->gas_thr = 8;
     if (const char* e = getenv("DE_V2_G")) a->gas_thr = atoi(e);
+    a->chunk = 64;
+    if (const char* e = getenv("DE_V2_CHUNK")) { int v = atoi(e); if (v >= 1) a->chunk = v; }
     if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
     if (const char* e = getenv("DE_V2_A")) a->heavy_thr = atoi(e);
     if (const char* e = getenv("DE_V2_B")) a->tune_b = atoi(e);
@@ -572,7 +574,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
 }
 
 int de_debug_math(de_ctx* c, int fn, const float* a, const float* b, float* out, uint64_t n) {
-    if (!c || !a || !out || fn < 0 || fn > 10) return fail(DE_ERR_INVALID, "bad arguments");
+    if (!c || !a || !out || fn < 0 || fn > 11) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&da, n * sizeof(float)));

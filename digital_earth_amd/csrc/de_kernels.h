@@ -65,6 +65,7 @@ struct RenderArgs {
     uint2* contrib;               // v2: per-sample (radiance bits, wavelength node), index = work item
     int pend_thr;                 // v2: lanes that must wait before the transition pass runs
     int heavy_thr;                // v2: stashed paths of one kind that trigger a batch (env DE_V2_A)
+    int chunk;                    // v2: work items per counter fetch (env DE_V2_CHUNK)
     int gas_thr;                  // v2: lanes waiting in the GAS class that make its body run (env DE_V2_G)
     int tune_b;                   // v2: below this many iterating lanes everything that waits is processed (env DE_V2_B)
 };

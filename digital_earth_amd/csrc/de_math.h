@@ -54,6 +54,19 @@ DE_DEV float de_div_rc_pinf(float x, float c, float rc) {
     return (x == __builtin_inff()) ? x : q;
 }
 
+// a / b for a divisor that is shared by several numerators (normalising a vector): y = RN(1/b) is computed once with
+// the real divide, then each quotient takes 5 operations — two rounds of (residual, correction).  After the first round
+// q1 is within 1 ulp of a/b, so by Markstein's theorem (y = RN(1/b), r = a - b*q1 exact in an fma) the second round
+// returns RN(a/b).  Valid away from under/overflow (|a/b|, |a|, |b| in 2^+-60); tests/test_gpu_parity.py::
+// test_shared_divisor_division checks it against the divide on 2^28 operand pairs.
+DE_DEV float de_div_y(float a_, float b, float y) {
+    float q = a_ * y;
+    float r = de_fma(-q, b, a_);
+    q = de_fma(r, y, q);
+    r = de_fma(-q, b, a_);
+    return de_fma(r, y, q);
+}
+
 // sqrt for x = 0 or a normal x in [2^-60, 2^60]: v_sqrt_f32 (<= 1 ulp) corrected to the nearest value with two residual
 // tests — the core of the compiler's IEEE expansion without its denormal scaling and class checks (21 -> 9 operations).
 // tests/test_gpu_parity.py::test_fast_sqrt_is_correctly_rounded compares it with the IEEE result for every significand

@@ -143,7 +143,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 }  // namespace v2
 
 #ifndef DE_V2_CHUNK
-#define DE_V2_CHUNK 512            // work items a wave takes from the device-wide counter per atomic
+#define DE_V2_CHUNK 64            // default work items a wave takes from the device-wide counter per atomic (RenderArgs::chunk)
 #endif
 #define DE_V2_STASH_FIELDS 36
 #ifndef DE_V2_MIN_WAVES
@@ -330,7 +330,8 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         if (peri2 > K * K) { tap_escaped = true; tap_do = false; }
                     }
                     if (tap_do) {
-                        const vec3 n = Q / tap_len;
+                        const float inv_len = 1.0f / tap_len;          // one real divide, three 5-operation quotients (de_div_y)
+                        const vec3 n = v3(de_div_y(Q.x, tap_len, inv_len), de_div_y(Q.y, tap_len, inv_len), de_div_y(Q.z, tap_len, inv_len));
                         if (MODE) wk.taps_r8++;
                         TexR8 T = a.topo;   // per-lane map select (two maps only in this class)
                         T.data = cloud ? a.clouds.data : a.topo.data;
@@ -668,11 +669,11 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 w_lo += min((uint32_t)__popcll(m_need), avail);
                 if (__ballot(need && !got) == 0ull) break;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.work_counter, (uint32_t)DE_V2_CHUNK);
+                if (lane == 0) base = atomicAdd(a.work_counter, (uint32_t)a.chunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= total_items) break;
                 w_lo = base;
-                w_hi = min(base + (uint32_t)DE_V2_CHUNK, total_items);
+                w_hi = min(base + (uint32_t)a.chunk, total_items);
             }
             if (need) {
                 if (!got) {
