@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--preset", default=None, help="camera preset file name under digital_earth_amd/data/configs")
     ap.add_argument("--cloud-heavy", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=1, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
     return ap.parse_args()
 
 
@@ -63,9 +63,15 @@ def cpu_baseline(r, args):
     p = ob.DeParams()
     ctypes.memmove(ctypes.byref(p), ctypes.byref(r._params), ctypes.sizeof(p))
     o.set_params(p)
+    # bounded sample: 1 spp first; then as many more samples per pixel as fit in ~15 s (at most --cpu-spp, default 8)
     t0 = time.perf_counter()
-    o.accumulate(args.cpu_spp, r.seed)
+    o.accumulate(1, r.seed)
+    t1 = time.perf_counter() - t0
+    extra = int(min(max(args.cpu_spp - 1, 0), max(0.0, 15.0 / max(t1, 1e-3) - 1.0)))
+    if extra > 0:
+        o.accumulate(extra, r.seed)
     dt = time.perf_counter() - t0
+    args.cpu_spp = 1 + extra
     n = W * H * args.cpu_spp
     out = {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": o.threads, "kind": "port",
            "sample": "full %dx%d frame at %d spp (%d samples, %.1f s), same maps/camera/seed; C++ restatement of the "
@@ -154,10 +160,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # roofline of the dominant kernel (render_kernel): algorithmic bytes per launch / measured launch duration.
-    # B_sample = 24/spp (one HDR read-modify-write per pixel per launch) + 4 B per r8 tap + 16 B per colour tap
+    # B_sample = 8 B contribution record + 4 B per r8 tap + 16 B per colour tap
     # (SURVEY §8d); samples per launch on this rank = its share of the frame.
     my_samples = int(parallel.owned_pixel_mask(W, H, rank, world).sum()) * spp
-    b_sample = 24.0 / spp + 4.0 * n_r8 + 16.0 * n_rgb
+    # render_kernel_v2 writes one 8-byte (radiance, wavelength node) record per sample; the HDR read-modify-write
+    # (24 B per pixel per launch) happens in accumulate_kernel
+    b_sample = 8.0 + 4.0 * n_r8 + 16.0 * n_rgb
     achieved_gbps = b_sample * my_samples / (avg_kernel_ms * 1e-3) / 1e9
     traffic = None
     traffic_note = "not collected in this run (see profiles/ for the rocprofv3 --pmc pass)"
