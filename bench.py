@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--tex-quality", type=int, default=2)
     ap.add_argument("--preset", default=None, help="camera preset file name under digital_earth_amd/data/configs")
     ap.add_argument("--cloud-heavy", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="independent frame contexts alternated step by step (tail overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
     return ap.parse_args()
@@ -106,16 +107,23 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
     W, H, spp = args.width, args.height, args.spp
-    r = Renderer((W, H), (0, 1, 0), device=device_index, texture_source="synthetic", texture_quality=args.tex_quality,
-                 cloud_heavy=args.cloud_heavy, seed=0)
-    if args.preset:
-        apply_preset(r, args.preset)
-    r.copy_textures()
-    frame = parallel.DistributedFrame(r, rank, world, device_index)
+    # Frames in flight: each has its own context (maps, buffers) and HIP stream; consecutive steps alternate between them,
+    # so the tail of one frame (a few very long paths finishing) overlaps the start of the next.  Every step is still a
+    # complete frame (reset, spp samples per pixel, reduce, display).
+    frames = []
+    for k in range(max(1, args.frames_in_flight)):
+        rk = Renderer((W, H), (0, 1, 0), device=device_index, texture_source="synthetic", texture_quality=args.tex_quality,
+                      cloud_heavy=args.cloud_heavy, seed=0)
+        if args.preset:
+            apply_preset(rk, args.preset)
+        rk.copy_textures()
+        frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index)))
+    r, frame = frames[0].r, frames[0]
 
     def barrier():
+        for f in frames:
+            f.synchronize()
         torch.cuda.synchronize()
-        r.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -129,12 +137,12 @@ def main():
     n_r8 = cnt["taps_r8"] / max(cnt["samples"], 1)
     n_rgb = cnt["taps_rgb8"] / max(cnt["samples"], 1)
 
-    for _ in range(args.warmup):
-        frame.render_frame(spp)
+    for i in range(args.warmup):
+        frames[i % len(frames)].render_frame(spp)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame.render_frame(spp)
+    for i in range(args.steps):
+        frames[i % len(frames)].render_frame(spp)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -191,6 +199,7 @@ def main():
         "config": {"workload": "%dx%d, %d spp, full spectral Rayleigh+Mie+O3+clouds, quality-%d synthetic maps, %s, "
                                "BASELINE configs[1]" % (W, H, spp, args.tex_quality, args.preset or "default camera"),
                    "parallelism": "tile-partition x%d + RCCL reduce" % world if world > 1 else "single GPU",
+                   "frames_in_flight": len(frames),
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,

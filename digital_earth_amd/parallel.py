@@ -44,22 +44,30 @@ class DistributedFrame:
     """Binds a Renderer to this process's rank: torch owns the HDR buffer (so RCCL can reduce it in place) and the
     renderer launches on torch's current stream (so the collective is ordered after the render kernel)."""
 
-    def __init__(self, renderer, rank, world, device_index):
+    def __init__(self, renderer, rank, world, device_index, stream=None):
         import torch
         self.torch = torch
         self.r = renderer
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device_index)
+        # Each frame in flight has its own stream: the tail of one frame's render kernel (a few long paths) then
+        # overlaps the start of the next frame instead of idling the GPU.
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         W, H = renderer.image_res
         self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
         renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
-        renderer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        renderer.set_stream(self.stream.cuda_stream)
         renderer.set_tile_partition(rank, world)
 
     def render_frame(self, spp):
-        """reset -> accumulate(spp) on this rank's tiles -> reduce to rank 0 -> display transform on rank 0 (device)."""
-        self.r.reset_framebuffer()            # zeroes the bound HDR buffer on the shared stream
-        self.r.accumulate(spp)
-        reduce_hdr(self.hdr, dst=0)
-        if self.rank == 0:
-            self.r.render_to_image_device()
+        """reset -> accumulate(spp) on this rank's tiles -> reduce to rank 0 -> display transform on rank 0 (device).
+        Everything is enqueued on this frame's stream; nothing here waits for the GPU."""
+        with self.torch.cuda.stream(self.stream):
+            self.r.reset_framebuffer()        # zeroes the bound HDR buffer on the frame's stream
+            self.r.accumulate(spp)
+            reduce_hdr(self.hdr, dst=0)
+            if self.rank == 0:
+                self.r.render_to_image_device()
+
+    def synchronize(self):
+        self.stream.synchronize()
