@@ -338,3 +338,52 @@ def test_shared_divisor_division(Renderer):
             b = (6.371e6 + rng.uniform(0, 1.2e5, n)).astype(np.float32)
             a = (rng.uniform(-1, 1, n) * b).astype(np.float32)
         assert (r.debug_math(11, a, b).view(np.uint32) == r.debug_math(7, a, b).view(np.uint32)).all(), rep
+
+
+def test_full_size_frame_properties(Renderer, lut_arrays):
+    """BASELINE.json's full frame size (1920x1080): properties that do not need the oracle to render the whole frame.
+    (a) the oracle renders a sparse subset of 8x8 tiles (rank 7 of 61 in the tile partition) of the SAME full frame and
+        those pixels must match the GPU frame bit for bit;  (b) the 8-rank tiled frame equals the 1-rank frame;
+    (c) every pixel is rendered by exactly one rank (sum of the rank frames == frame, x + 0 exact)."""
+    from digital_earth_amd import parallel
+    W, H, SPP = 1920, 1080, 2
+    r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(4096, 2048), seed=11)
+    r.copy_textures()
+    r.accumulate(SPP)
+    full = r.fetch_hdr()
+    assert np.isfinite(full).all() and full.max() > 0
+    # (a)
+    texels = [r.download_texture(s) for s in range(7)]
+    o = make_oracle(W, H, lut_arrays, texels, r._params)
+    o.accumulate(SPP, 11, 7, 61)
+    part = o.fetch_hdr()
+    mask = parallel.owned_pixel_mask(W, H, 7, 61)
+    assert mask.sum() > 30000
+    assert (part[~mask] == 0).all()
+    assert (part[mask].view(np.uint32) == full[mask].view(np.uint32)).all()
+    # (b), (c)
+    total = np.zeros_like(full)
+    for rank in range(8):
+        r.reset_framebuffer()
+        r.set_tile_partition(rank, 8)
+        r.accumulate(SPP)
+        f = r.fetch_hdr()
+        m = parallel.owned_pixel_mask(W, H, rank, 8)
+        assert (f[~m] == 0).all()
+        total += f
+    assert (total.view(np.uint32) == full.view(np.uint32)).all()
+
+
+def test_edge_cases_of_accumulate(Renderer):
+    from digital_earth_amd._native import DigitalEarthError
+    r = Renderer((256, 256), (0, 1, 0), texture_source="constant")
+    r.accumulate(0)                                   # nothing to do: state unchanged
+    assert r.current_spp == 0 and (r.fetch_hdr() == 0).all()
+    with pytest.raises(DigitalEarthError):            # 65536 pixels x 70000 spp >= 2^32 work items: must be split by the caller
+        r.accumulate(70000)
+    with pytest.raises(ValueError):
+        r.set_tile_partition(3, 2)
+    r.set_tile_partition(1, 2)
+    r.accumulate(1)
+    h = r.fetch_hdr()
+    assert (h[0:8, 0:8] == 0).all() and (h[8:16, 0:8] != 0).any()      # tile (0,0) belongs to rank 0, tile (1,0) to rank 1
