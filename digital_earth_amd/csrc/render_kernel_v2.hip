@@ -388,6 +388,10 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         trn *= 1.0f - gas_div(sum);
                         if (trn < 1e-5f) { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
                     }
+                    if (is_gas(state) && !(t < tmax)) {            // loop-head test, see the cloud class
+                        if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; enter_cloud(0); }
+                        else { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
+                    }
                 }
             }
         }
@@ -422,6 +426,12 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                         } else {
                             trn *= 1.0f - de_div_rc_ng(es, maxc, rmaxc);
                             if (trn < 1e-5f) state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
+                        }
+                        // `while t < t_max` at the loop head (pathtracer.py:91,130): implied by the test above unless t is NaN
+                        // (a degenerate camera); without it a NaN path would iterate for ever
+                        if (is_cloud_tap(state) && !(t < tmax)) {
+                            if (state == S_DT_C) state = S_AFTER_DT_C;
+                            else state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
                         }
                     } else {
                         float sdf = len - DE_PLANET_R - fc.land_height_scale * tex;

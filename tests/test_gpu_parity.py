@@ -387,3 +387,16 @@ def test_edge_cases_of_accumulate(Renderer):
     r.accumulate(1)
     h = r.fetch_hdr()
     assert (h[0:8, 0:8] == 0).all() and (h[8:16, 0:8] != 0).any()      # tile (0,0) belongs to rank 0, tile (1,0) to rank 1
+
+
+def test_degenerate_camera_terminates(Renderer, lut_arrays):
+    """look_at == camera_pos makes every ray direction NaN (normalized() of a zero vector, renderer.py:272).  The reference's
+    loops all end on NaN comparisons and the NaN guard zeroes the radiance (pathtracer.py:466-467); the kernel must
+    terminate too, and agree with the oracle."""
+    r = Renderer((64, 32), (0, 1, 0), texture_source="synthetic", texture_size=(512, 256))
+    r.set_look_at(*[float(x) for x in r.camera_pos[None]])
+    r.copy_textures()
+    o = make_oracle(64, 32, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
+    r.accumulate(1); o.accumulate(1, 0)
+    g, c = r.fetch_hdr(), o.fetch_hdr()
+    assert (g == 0).all() and (c == 0).all()
