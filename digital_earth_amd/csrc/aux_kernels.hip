@@ -30,6 +30,7 @@ __global__ void setup_kernel(SetupArgs s) {
         de_sincos(p.sun_path_rot, &s_rot, &c_rot);
         de_sincos(p.sun_angle, &s_ang, &c_ang);
         fc.light_dir = v3(-s_ang, c_ang * -s_rot, c_ang * c_rot);      // :301-302
+        make_orthonormal_basis(fc.light_dir, &fc.sun_x, &fc.sun_y);
         fc.land_height_scale = p.land_height_scale;
         int topo_res = p.topo_res_override > 0 ? p.topo_res_override : s.topo_w;
         fc.normal_eps = (float)(M_PI * 6371e3 / (double)topo_res);     // pathtracer.py:20

@@ -11,6 +11,7 @@ struct FrameConsts {
     float fov, aspect_ratio, aspect_scale;   //                               renderer.py:271-275
     float inv_h_dummy;
     vec3 light_dir;                          //                               renderer.py:301-302
+    vec3 sun_x, sun_y;                       // make_orthonormal_basis(light_dir), lib/math_utils.py:55-60 (same for every light sample)
     float sun_cos_angle, sun_angular_radius; //                               renderer.py:297-300
     float land_height_scale;
     float normal_eps;                        // pi * planet_r / TOPO_W        pathtracer.py:20

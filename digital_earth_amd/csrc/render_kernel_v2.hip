@@ -485,7 +485,11 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
                 if (cloud_event > 0 && (t < rmo_t || gas_event == EV_NULL)) { tt = t; id = CLOUD_ID; event = cloud_event; }
                 if (sc > 9 && id == CLOUD_ID) id = ISOTROPIC_CLOUD_ID;
                 ev_id = id;
-                LD = tangent_space_apply(fc.light_dir, sample_cone(rng, fc.sun_cos_angle));
+                {   // sample_cone_oriented (lib/sampling.py:25-28) with the light direction's basis taken from the frame constants
+                    const vec3 cv = sample_cone(rng, fc.sun_cos_angle);
+                    const vec3 bx = fc.sun_x, by = fc.sun_y, bn = fc.light_dir;
+                    LD = v3((bx.x * cv.x + by.x * cv.y) + bn.x * cv.z, (bx.y * cv.x + by.y * cv.y) + bn.y * cv.z, (bx.z * cv.x + by.z * cv.y) + bn.z * cv.z);
+                }
                 if (event == EV_ABSORB) {
                     state = S_END;
                 } else if (event == EV_SCATTER) {
