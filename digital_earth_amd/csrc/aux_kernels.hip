@@ -48,6 +48,9 @@ __global__ void setup_kernel(SetupArgs s) {
         // double on the host — see de_api.hip:opendrt_consts
         fc.drt_m = s.drt[0]; fc.drt_s = s.drt[1]; fc.drt_fl = s.drt[2];
         fc.drt_ds = s.drt[3]; fc.drt_clamp_max = s.drt[4]; fc.drt_dch_s = s.drt[5];
+        for (int i = 0; i < 9; ++i) { fc.agx_srgb_to_xyz[i] = s.agx[i]; fc.agx_xyz_to_adjusted[i] = s.agx[9 + i]; }
+        fc.agx_x_pivot = s.agx[18]; fc.agx_y_pivot = s.agx[19]; fc.agx_toe_scale = s.agx[20]; fc.agx_shoulder_scale = s.agx[21];
+        fc.use_agx = (p.flags & DE_FLAG_AGX) ? 1 : 0;
         vec3 w = v3(0.25f, 1.0f, 0.35f);                               // lib/OpenDRT.py:369
         fc.drt_w = w / length(w);                                      // :370
         *s.fc = fc;
@@ -173,6 +176,33 @@ DE_DEV vec3 openDR_transform(const FrameConsts& k, float p_R, float p_G, float p
     rgb = rats * ts;
     return v3(de_min(rgb.x, k.drt_clamp_max), de_min(rgb.y, k.drt_clamp_max), de_min(rgb.z, k.drt_clamp_max));
 }
+// lib/AgX.py:87-159 (the alternative display transform kept behind a comment at renderer.py:356); display_transform has
+// no `return` in the reference: its final `workingColor` is the value.
+DE_DEV float agx_hyperbolic(float x, float power) { return x / de_pow(1.0f + de_pow(x, power), 1.0f / power); }   // :103-105
+DE_DEV float agx_full_curve(const FrameConsts& k, float x) {                                                       // :111-127
+    const bool upper = x >= k.agx_x_pivot;
+    const float scale = upper ? k.agx_shoulder_scale : -k.agx_toe_scale;
+    const float term = ((float)2.3 * (x - k.agx_x_pivot)) / scale;                                                  // :107-109
+    const float power = (scale < 0.0f) ? (float)1.9 : (float)3.1;
+    return scale * agx_hyperbolic(term, power) + k.agx_y_pivot;
+}
+DE_DEV vec3 agx_display_transform(const FrameConsts& k, vec3 c) {                                                  // :130-159
+    const float* m1 = k.agx_srgb_to_xyz;
+    const float* m2 = k.agx_xyz_to_adjusted;
+    vec3 xyz = v3((m1[0] * c.x + m1[1] * c.y) + m1[2] * c.z, (m1[3] * c.x + m1[4] * c.y) + m1[5] * c.z, (m1[6] * c.x + m1[7] * c.y) + m1[8] * c.z);
+    vec3 adj = v3((m2[0] * xyz.x + m2[1] * xyz.y) + m2[2] * xyz.z, (m2[3] * xyz.x + m2[4] * xyz.y) + m2[5] * xyz.z,
+                  (m2[6] * xyz.x + m2[7] * xyz.y) + m2[8] * xyz.z);
+    const float lo = -10.0f, hi = 6.5f, total = (float)(6.5 - -10.0);
+    float v[3] = {adj.x, adj.y, adj.z}, o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float l = de_min(de_max(lo, de_log(v[i] / (float)0.18) / (float)0.6931471805599453), hi);   // :88-95; log of a non-positive channel -> MIN_EV
+        float x = (l - lo) / total;
+        o[i] = de_clamp(agx_full_curve(k, x), 0.0f, 1.0f);
+    }
+    vec3 w = v3(o[0], o[1], o[2]);
+    return mix3(lum3(w), w, (float)1.4);
+}
 }  // namespace
 
 __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
@@ -187,6 +217,12 @@ __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
     const float* px = a.hdr + (size_t)idx * 3;
     float samples = (float)a.samples;
     vec3 linear = v3(px[0] / samples, px[1] / samples, px[2] / samples) * darken * k.exposure_scale;   // :355
+    float* o = a.image + ((size_t)i * a.H + j) * 3;                    // (W, H, 3)
+    if (k.use_agx) {                                                   // :356: srgb_transfer(agx.display_transform(linear))
+        vec3 ax = agx_display_transform(k, linear);
+        o[0] = srgb_transfer1(ax.x); o[1] = srgb_transfer1(ax.y); o[2] = srgb_transfer1(ax.z);
+        return;
+    }
     vec3 t = openDR_transform(k, linear.x, linear.y, linear.z);        // :357
     // camera_response, renderer.py:333-344
     t = v3(de_clamp(t.x, 0.0f, 1.0f), de_clamp(t.y, 0.0f, 1.0f), de_clamp(t.z, 0.0f, 1.0f));
@@ -196,7 +232,6 @@ __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
     float blue = tap_f3(a.crf, de_min(t.z + u_offset, u_hi), k.crf_slice_v, a.clamp != 0).z;
     vec3 cam = v3(de_clamp(red, 0.0f, 1.0f), de_clamp(green, 0.0f, 1.0f), de_clamp(blue, 0.0f, 1.0f));
     vec3 g = v3(de_pow(cam.x, k.gamma), de_pow(cam.y, k.gamma), de_pow(cam.z, k.gamma));   // :360
-    float* o = a.image + ((size_t)i * a.H + j) * 3;                    // (W, H, 3)
     o[0] = srgb_transfer1(g.x); o[1] = srgb_transfer1(g.y); o[2] = srgb_transfer1(g.z);    // :362-365
 }
 

@@ -86,6 +86,53 @@ void opendrt_consts(float* m, float* s, float* fl, float* ds, float* clamp_max, 
     *m = (float)m_d; *s = (float)s_d; *fl = (float)flare; *ds = (float)ds_d; *clamp_max = (float)cm; *dch_s = (float)(dch / s_d);
 }
 
+// lib/AgX.py:22-85, 99-101, 133-150: matrices and curve scales of the AgX display transform — constant expressions of
+// module constants (primaries, COMPRESSION = 0.15, SLOPE = 2.3, TOE_POWER = 1.9, SHOULDER_POWER = 3.1, EV range
+// [-10, 6.5]), evaluated in double and rounded to f32.
+struct M3d { double m[9]; };
+M3d m3_inverse(const M3d& a) {
+    const double* m = a.m;
+    double d = m[0] * (m[4] * m[8] - m[7] * m[5]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    double id = 1.0 / d;
+    M3d c;
+    c.m[0] = id * (m[4] * m[8] - m[7] * m[5]); c.m[1] = id * (m[2] * m[7] - m[1] * m[8]); c.m[2] = id * (m[1] * m[5] - m[2] * m[4]);
+    c.m[3] = id * (m[5] * m[6] - m[3] * m[8]); c.m[4] = id * (m[0] * m[8] - m[2] * m[6]); c.m[5] = id * (m[3] * m[2] - m[0] * m[5]);
+    c.m[6] = id * (m[3] * m[7] - m[6] * m[4]); c.m[7] = id * (m[6] * m[1] - m[0] * m[7]); c.m[8] = id * (m[0] * m[4] - m[3] * m[1]);
+    return c;
+}
+void xy_unproject(double x, double y, double* X, double* Y, double* Z) {
+    *X = 0; *Y = 0; *Z = 0;
+    if (y != 0.0) { *Y = 1.0; *X = x / y; *Z = (1.0 - x - y) / y; }
+}
+M3d primaries_to_matrix(const double r[2], const double g[2], const double b[2], const double w[2]) {
+    double Xr, Yr, Zr, Xg, Yg, Zg, Xb, Yb, Zb, Xw, Yw, Zw;
+    xy_unproject(r[0], r[1], &Xr, &Yr, &Zr); xy_unproject(g[0], g[1], &Xg, &Yg, &Zg);
+    xy_unproject(b[0], b[1], &Xb, &Yb, &Zb); xy_unproject(w[0], w[1], &Xw, &Yw, &Zw);
+    M3d t = {{Xr, Xg, Xb, 1.0, 1.0, 1.0, Zr, Zg, Zb}};
+    M3d inv = m3_inverse(t);
+    double sx = inv.m[0] * Xw + inv.m[1] * Yw + inv.m[2] * Zw;
+    double sy = inv.m[3] * Xw + inv.m[4] * Yw + inv.m[5] * Zw;
+    double sz = inv.m[6] * Xw + inv.m[7] * Yw + inv.m[8] * Zw;
+    M3d o = {{sx * Xr, sy * Xg, sz * Xb, sx * Yr, sy * Yg, sz * Yb, sx * Zr, sy * Zg, sz * Zb}};
+    return o;
+}
+double agx_scale(double x_pivot, double y_pivot, double slope_pivot, double power) {
+    return pow(pow(slope_pivot * x_pivot, -power) * (pow(slope_pivot * (x_pivot / y_pivot), power) - 1.0), -1.0 / power);
+}
+void agx_consts(float* out22) {
+    const double R[2] = {0.64, 0.33}, G[2] = {0.3, 0.6}, B[2] = {0.15, 0.06}, W[2] = {0.3127, 0.3290};
+    M3d s2x = primaries_to_matrix(R, G, B, W);
+    const double sf = 1.0 / (1.0 - 0.15);
+    double r2[2] = {(R[0] - W[0]) * sf + W[0], (R[1] - W[1]) * sf + W[1]}, g2[2] = {(G[0] - W[0]) * sf + W[0], (G[1] - W[1]) * sf + W[1]};
+    double b2[2] = {(B[0] - W[0]) * sf + W[0], (B[1] - W[1]) * sf + W[1]};
+    M3d x2a = m3_inverse(primaries_to_matrix(r2, g2, b2, W));
+    for (int i = 0; i < 9; ++i) { out22[i] = (float)s2x.m[i]; out22[9 + i] = (float)x2a.m[i]; }
+    const double xp = 10.0 / (6.5 + 10.0), yp = 0.5;
+    out22[18] = (float)xp; out22[19] = (float)yp;
+    out22[20] = (float)agx_scale(xp, yp, 2.3, 1.9);
+    out22[21] = (float)agx_scale(1.0 - xp, 1.0 - yp, 2.3, 3.1);
+}
+
 }  // namespace
 
 struct de_ctx {
@@ -163,6 +210,7 @@ int run_setup(de_ctx* c) {
     SetupArgs s;
     s.p = c->p;
     opendrt_consts(&s.drt[0], &s.drt[1], &s.drt[2], &s.drt[3], &s.drt[4], &s.drt[5]);
+    agx_consts(s.agx);
     s.W = c->W; s.H = c->H;
     s.topo_w = c->tex[DE_TEX_TOPOGRAPHY].w > 0 ? c->tex[DE_TEX_TOPOGRAPHY].w : 1;
     s.n_crf = c->n_crf;

@@ -26,6 +26,10 @@ struct FrameConsts {
     float vig_strength, vig_radius, vig_cx, vig_cy;
     float drt_m, drt_s, drt_fl, drt_ds, drt_clamp_max, drt_dch_s;
     vec3 drt_w;                              // normalised (rw, 1, bw)        lib/OpenDRT.py:369-370
+    // AgX alternative display transform (lib/AgX.py; DE_FLAG_AGX): matrices and curve scales, host double -> f32
+    float agx_srgb_to_xyz[9], agx_xyz_to_adjusted[9];
+    float agx_x_pivot, agx_y_pivot, agx_toe_scale, agx_shoulder_scale;
+    int use_agx;
 };
 
 // One node of spectrum_sample's bisection tree (lib/colour.py:24-39): 8 steps reach one of 256 leaves; an exact
@@ -80,6 +84,7 @@ struct SetupArgs {
     const float* srgb2spec;   // 300 x 3
     const float* o3;          // 441
     float drt[6];             // OpenDRT m, s, fl, ds, clamp_max, dch_s (host, double -> f32)
+    float agx[22];            // AgX: srgb_to_xyz[9], xyz_to_adjusted[9], x_pivot, y_pivot, toe_scale, shoulder_scale
     FrameConsts* fc;
     LambdaNode* nodes;
     float* node_val;

@@ -296,6 +296,13 @@ class Renderer:
             raise ValueError(name)
         self.set_flag(_native.DE_FLAG_RAY_MARCHER, name == "ray_marcher")
 
+    def set_display_transform(self, name):
+        """'opendrt' (what the reference runs: OpenDRT + camera response + gamma, renderer.py:357-362) or 'agx'
+        (the alternative kept behind a comment at renderer.py:356, lib/AgX.py)."""
+        if name not in ("opendrt", "agx"):
+            raise ValueError(name)
+        self.set_flag(_native.DE_FLAG_AGX, name == "agx")
+
     def set_topo_res_override(self, res):
         self._params.topo_res_override = int(res)
         self._push_params()
@@ -379,6 +386,22 @@ class Renderer:
             raise ValueError("hdr must have shape (W, H, 3)")
         check(self._lib.de_upload_hdr(self._h, hdr.ctypes.data, int(spp)))
         self.current_spp = int(spp)
+
+    def save_checkpoint(self, path):
+        """Persist the progressive state — HDR sums, sample count, RNG base seed and the scalar parameters — so that a long
+        render (BASELINE cfg5: 1024 spp) can be resumed.  The reference keeps this state in memory only (renderer.py:23,25)."""
+        np.savez(path, hdr=self.fetch_hdr(), spp=np.int64(self.current_spp), seed=np.uint64(self.seed),
+                 params=np.frombuffer(bytes(self._params), dtype=np.uint8), image_res=np.array(self.image_res))
+
+    def load_checkpoint(self, path):
+        """Resume from save_checkpoint(): the next accumulate() continues with sample index `spp`, bit-identically."""
+        z = np.load(path)
+        if tuple(int(x) for x in z["image_res"]) != self.image_res:
+            raise ValueError("checkpoint is %s, renderer is %s" % (tuple(z["image_res"]), self.image_res))
+        ctypes.memmove(ctypes.byref(self._params), z["params"].tobytes(), ctypes.sizeof(self._params))
+        self._push_params()
+        self.seed = int(z["seed"])
+        self.upload_hdr(z["hdr"], int(z["spp"]))
 
     def set_current_spp(self, spp):
         self.current_spp = int(spp)

@@ -400,3 +400,44 @@ def test_degenerate_camera_terminates(Renderer, lut_arrays):
     r.accumulate(1); o.accumulate(1, 0)
     g, c = r.fetch_hdr(), o.fetch_hdr()
     assert (g == 0).all() and (c == 0).all()
+
+
+def test_agx_display_transform(Renderer, lut_arrays):
+    """DE_FLAG_AGX: srgb_transfer(agx.display_transform(linear)) (renderer.py:356, lib/AgX.py) vs the oracle."""
+    W, H = 64, 32
+    r = Renderer((W, H), (0, 1, 0), texture_source="constant")
+    r.copy_textures()
+    r.set_display_transform("agx")
+    rng = np.random.default_rng(17)
+    hdr = (rng.lognormal(-1.0, 2.0, size=(W, H, 3)) * rng.uniform(0, 1, size=(W, H, 1))).astype(np.float32)
+    hdr[0, 0] = 0.0; hdr[1, 1] = [-0.5, 2.0, 1e-6]; hdr[2, 2] = 0.18 * 4 / 2 ** 2.5
+    r.upload_hdr(hdr, 4)
+    o = make_oracle(W, H, lut_arrays, None, r._params)
+    o.set_hdr(hdr, 4)
+    g, c = r.fetch_image(), o.fetch_image()
+    assert np.isfinite(g).all()
+    assert np.abs(g - c).max() <= 1e-5
+    # middle grey at the centre of the vignette-free pixel maps to AgX's y_pivot 0.5 -> sRGB 0.7354
+    r.vignette_strength = 0.0
+    o2 = make_oracle(W, H, lut_arrays, None, r._params); o2.set_hdr(hdr, 4)
+    g2 = r.fetch_image()
+    assert np.abs(g2 - o2.fetch_image()).max() <= 1e-5
+    assert abs(g2[2, 2, 1] - 0.7354) < 2e-3
+    r.set_display_transform("opendrt")
+    assert np.abs(r.fetch_image() - g2).max() > 1e-3
+
+
+def test_checkpoint_file_round_trip(Renderer, tmp_path):
+    kw = dict(texture_source="synthetic", texture_size=(1024, 512))
+    a = Renderer((64, 64), (0, 1, 0), seed=21, **kw); a.set_fov(0.4); a.set_exposure(1.5)
+    a.accumulate(3)
+    a.save_checkpoint(str(tmp_path / "state.npz"))
+    a.accumulate(2)
+    want = a.fetch_hdr()
+    b = Renderer((64, 64), (0, 1, 0), **kw)
+    b.load_checkpoint(str(tmp_path / "state.npz"))
+    assert b.current_spp == 3 and b.seed == 21 and abs(b.exposure[None] - 1.5) < 1e-7
+    b.accumulate(2)
+    assert (b.fetch_hdr().view(np.uint32) == want.view(np.uint32)).all()
+    with pytest.raises(ValueError):
+        Renderer((32, 32), (0, 1, 0), **kw).load_checkpoint(str(tmp_path / "state.npz"))

@@ -201,3 +201,13 @@ def test_earth_brdf_energy_bound_and_reciprocity_of_terms():
             # white furnace bound: uniform-hemisphere estimate of the albedo integral of brdf * cos stays below 1
             est = (o[:, 0] * o[:, 1]).mean() * 2 * np.pi
             assert est < 1.0, (v, ocean, est)
+
+
+def test_agx_known_points():
+    """lib/AgX.py: scene middle grey (0.18) sits on the curve's pivot (y = 0.5); black -> 0; the curve is monotonic and
+    bounded by [0, 1] for achromatic input."""
+    a = ev("agx", [[0.18, 0.18, 0.18], [0.0, 0.0, 0.0], [1e4, 1e4, 1e4]], 3)
+    assert np.allclose(a[0], 0.5, atol=1e-5) and (a[1] == 0).all() and np.allclose(a[2], 1.0, atol=1e-4)
+    g = np.logspace(-4, 2, 200)
+    mono = ev("agx", np.repeat(g[:, None], 3, 1), 3)[:, 1]
+    assert (np.diff(mono) >= -1e-6).all() and mono.min() >= 0 and mono.max() <= 1
