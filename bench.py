@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--cloud-heavy", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="independent frame contexts alternated step by step (tail overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-world", type=int, default=0, help="1-GPU experiment: render only rank 0's share of an N-rank tile partition (no collective); not a bench line")
     ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
     return ap.parse_args()
 
@@ -118,6 +119,8 @@ def main():
             apply_preset(rk, args.preset)
         rk.copy_textures()
         frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index)))
+        if args.simulate_world > 1 and world == 1:
+            rk.set_tile_partition(0, args.simulate_world)
     r, frame = frames[0].r, frames[0]
 
     def barrier():

@@ -287,10 +287,13 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
     if (!march && c->kernel_variant == 2) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
         hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
-        const unsigned max_blocks = (unsigned)c->n_cus * 8u;
-        dim3 pgrid(grid.x > max_blocks ? max_blocks : grid.x);
-        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, block, 0, c->stream, a);
+        // waves: one per owned tile at most (a tile's first 64 work items), and no more than twice what the CUs hold
+        const unsigned waves_per_block = DE_V2_BLOCK / 64;
+        const unsigned max_waves = (unsigned)c->n_cus * 32u;
+        const unsigned n_waves = (unsigned)a.n_tiles > max_waves ? max_waves : (unsigned)a.n_tiles;
+        dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a);
+        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a);
         if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
         return;
     }

@@ -146,6 +146,12 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #define DE_V2_CHUNK 64            // default work items a wave takes from the device-wide counter per atomic (RenderArgs::chunk)
 #endif
 #define DE_V2_STASH_FIELDS 36
+#ifndef DE_V2_BLOCK
+// Threads per workgroup.  One wave per workgroup: the waves share nothing but a 1 KB table, and a workgroup's LDS and
+// wave slots are released only when ALL its waves have ended — with 4-wave workgroups the last long paths of a launch
+// kept 3 idle waves' worth of the machine from the next launch (frames in flight, bench.py).  16 x 10 KB = 160 KB LDS per CU.
+#define DE_V2_BLOCK 64
+#endif
 #ifndef DE_V2_MIN_WAVES
 #define DE_V2_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
@@ -155,7 +161,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 
 // MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
 template <bool CLAMP, int MODE>
-__global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a) {
+__global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a) {
     using namespace v2;
     // Persistent waves over WORK ITEMS = single samples.  Item w of the launch is sample (w / 64) % spp of lane-pixel
     // (w & 63) of owned tile a.tiles[w / (64 * spp)].  A wave takes chunks of DE_V2_CHUNK consecutive items from a
@@ -204,9 +210,9 @@ __global__ void __launch_bounds__(256, DE_V2_MIN_WAVES) render_kernel_v2(RenderA
     // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
     // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
     __shared__ float s_node_val[256];     // spectrum_sample's bisection values: 8 dependent reads per new path, from LDS
-    s_node_val[threadIdx.x] = a.node_val[threadIdx.x];
+    for (int i = (int)threadIdx.x; i < 256; i += DE_V2_BLOCK) s_node_val[i] = a.node_val[i];
     __syncthreads();
-    __shared__ uint32_t s_stash[4][DE_V2_STASH_FIELDS][64];
+    __shared__ uint32_t s_stash[DE_V2_BLOCK / 64][DE_V2_STASH_FIELDS][64];
     uint32_t* const slot = &s_stash[threadIdx.x >> 6][0][lane];
     int stash = 0;                        // 0 empty; 1/2/3 waiting for S_SC_FINISH / S_SURF_SETUP / S_SURF_FINISH; 4 ready to resume
 #define DE_XF(i, var) { const uint32_t tmp_ = slot[(i) * 64]; slot[(i) * 64] = __builtin_bit_cast(uint32_t, var); var = __builtin_bit_cast(decltype(var), tmp_); }
