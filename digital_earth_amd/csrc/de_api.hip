@@ -287,9 +287,13 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
     if (!march && c->kernel_variant == 2) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
         hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
-        // waves: one per owned tile at most (a tile's first 64 work items), and no more than twice what the CUs hold
+        // waves: one per owned tile at most (a tile's first 64 work items), and no more than the CUs hold at 4 waves/SIMD
+        // (more would only queue behind the resident ones and find the work counter exhausted; they would also keep the
+        // small kernels of the other frame in flight — accumulate, display, memsets — waiting for a slot)
         const unsigned waves_per_block = DE_V2_BLOCK / 64;
-        const unsigned max_waves = (unsigned)c->n_cus * 32u;
+        unsigned waves_per_cu = 16u;
+        if (const char* e = getenv("DE_V2_WPC")) { int v = atoi(e); if (v >= 1) waves_per_cu = (unsigned)v; }
+        const unsigned max_waves = (unsigned)c->n_cus * waves_per_cu;
         const unsigned n_waves = (unsigned)a.n_tiles > max_waves ? max_waves : (unsigned)a.n_tiles;
         dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
         if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a);
