@@ -141,6 +141,34 @@ DE_DEV float de_log(float x) {
     return (x != x || x < 0.0f) ? __builtin_nanf("") : res;
 }
 
+// de_log for an argument that is 0 or a normal number in (0, 1) — rng_next's k * 2^-24: the same operations as de_log
+// without the selects that cannot fire on that domain (subnormal scaling, +inf, NaN / negative).  Bit-identical to
+// de_log on all 2^24 such arguments (tests/test_gpu_parity.py::test_log_of_a_random_draw).
+DE_DEV float de_log_unit(float x) {
+    const uint32_t ix = de_f2u(x);
+    int e = (int)(ix >> 23) - 127;
+    float f = de_u2f((ix & 0x007fffffu) | 0x3f800000u);
+    if (f > 0x1.6a09e6p+0f) { f = f * 0.5f; e += 1; }
+    f = f - 1.0f;
+    float p = 0x1.16d79ep-4f;
+    p = de_fma(p, f, -0x1.dfb3a4p-4f);
+    p = de_fma(p, f, 0x1.e69804p-4f);
+    p = de_fma(p, f, -0x1.fbdbap-4f);
+    p = de_fma(p, f, 0x1.2338e2p-3f);
+    p = de_fma(p, f, -0x1.555e68p-3f);
+    p = de_fma(p, f, 0x1.99a4b4p-3f);
+    p = de_fma(p, f, -0x1.000002p-2f);
+    p = de_fma(p, f, 0x1.555548p-2f);
+    const float f2 = f * f;
+    const float fe = (float)e;
+    float y = (f * f2) * p;
+    y = de_fma(fe, DE_LN2_LO, y);
+    y = de_fma(-0.5f, f2, y);
+    const float z = f + y;
+    const float res = de_fma(fe, DE_LN2_HI, z);
+    return (x == 0.0f) ? -DE_INF : res;
+}
+
 DE_DEV void de_sincos(float x, float* s_out, float* c_out) {
     float k = de_floor(de_fma(x, DE_2OPI, 0.5f));
     float r = de_fma(-k, DE_PIO2_HI, x);

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                         maxv = ((sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT) * DE_CLOUDS_DENSITY;
                         rmaxv = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
                     } else { maxv = maxr; rmaxv = rmaxr; }
-                    const float neg_log = -de_log(rng_next(rng));
+                    const float neg_log = -de_log_unit(rng_next(rng));
                     float t_step = de_div_rc_pinf(neg_log, maxv, rmaxv);
                     if (any_slow_div) { if (rmaxv == 0.0f) t_step = neg_log / maxv; }
                     C = C + t_step * W;

@@ -256,6 +256,15 @@ def test_fast_sqrt_is_correctly_rounded(Renderer):
     assert r.debug_math(9, np.array([0.0], np.float32))[0] == 0.0
 
 
+def test_log_of_a_random_draw(Renderer):
+    """de_log_unit == de_log on every value rng_next can return (k * 2^-24, k = 0 .. 2^24 - 1)."""
+    r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
+    x = (np.arange(1 << 24, dtype=np.float64) * 2.0 ** -24).astype(np.float32)
+    a, b = r.debug_math(12, x), r.debug_math(1, x)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert np.isneginf(a[0]) and a[1] < -16.6
+
+
 def test_three_operation_division_by_literals(Renderer):
     """de_div_rc_ng(x, c) == x / c for every significand of x, for the literal divisors used by the kernels
     (the device-side twin of tools/verify_exact_div.c)."""
