@@ -179,6 +179,7 @@ def main():
     b_sample = 8.0 + 4.0 * n_r8 + 16.0 * n_rgb
     achieved_gbps = b_sample * my_samples / (avg_kernel_ms * 1e-3) / 1e9
     traffic = None
+    valu_insts = lane_util = None
     traffic_note = "not collected in this run (see profiles/ for the rocprofv3 --pmc pass)"
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(prof):
@@ -188,6 +189,7 @@ def main():
             if pj.get("workload") == "%dx%d_%dspp_q%d" % (W, H, spp, args.tex_quality) and world == 1:
                 traffic = pj.get("hbm_bytes_per_launch")
                 traffic_note = pj.get("note", "")
+                valu_insts, lane_util = pj.get("valu_insts_per_launch"), pj.get("valu_lane_utilisation")
         except Exception:
             pass
     # VALU view of the same launch: iterations x a per-iteration f32 op estimate (DESIGN.md "Algorithmic flops")
@@ -215,6 +217,15 @@ def main():
                  "tracking_steps_per_sample": cnt["tracking_steps"] / max(cnt["samples"], 1),
                  "vertices_per_sample": cnt["vertices"] / max(cnt["samples"], 1)},
     }
+    if valu_insts:
+        # The bound that actually holds: VALU issue.  Peak = one wave64 f32 instruction per 1.11 ns per SIMD, measured on
+        # this chip with tools/micro/dep_latency.hip (independent of chain count, reached with >= 3 waves per SIMD);
+        # instructions per launch = SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (same workload).
+        peak_ginst = 256 * 4 / 1.11                     # 1e9 wave-instructions / s
+        ach_ginst = valu_insts / (avg_kernel_ms * 1e-3) / 1e9
+        out["valu"]["issue"] = {"achieved": ach_ginst, "peak": peak_ginst, "unit": "1e9 wave64 VALU instructions/s",
+                                "frac": ach_ginst / peak_ginst, "insts_per_launch": valu_insts, "lane_utilisation": lane_util,
+                                "note": "peak measured by tools/micro/dep_latency.hip; instruction count from profiles/ (rocprofv3 SQ_INSTS_VALU)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, o = cpu_baseline(r, args)

@@ -48,6 +48,7 @@ def main(tag, workload="1920x1080_64spp_q2"):
             json.dump({"workload": workload, "hbm_bytes_per_launch": fetch_kb * 1024 + wr_kb * 1024,
                        "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
                        "tcc_miss_x_64B": (miss * 64 if miss else None), "profile": tag,
+                       "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"]) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None),
                        "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), per 64-spp launch. The guide's gfx950 "
                                "x2 correction is calibrated for wide coalesced streams; this kernel reads scattered 4-byte taps, and "
                                "raw FETCH_SIZE equals TCC_MISS_sum x 64 B here, so the raw value is reported and x2 kept as an upper bracket"},
