@@ -400,6 +400,7 @@ __global__ void math_kernel(int fn, const float* a, const float* b, float* out, 
         case 10: r = de_div_rc_ng(x, y, 1.0f / y); break;
         case 11: r = de_div_y(x, y, 1.0f / y); break;
         case 12: r = de_log_unit(x); break;
+        case 13: r = de_rcp_nr(x); break;
         default: r = 0.0f;
     }
     out[k] = r;

@@ -80,6 +80,15 @@ DE_DEV float de_sqrt_nr(float x) {
     return s;
 }
 
+// 1 / b for a normal b in [2^-60, 2^60]: v_rcp_f32 (<= 1 ulp) and one Newton step with the residual exact in an fma.
+// That yields RN(1/b) for every significand on gfx950 — checked exhaustively by tests/test_gpu_parity.py::
+// test_fast_reciprocal_is_correctly_rounded — in 3 operations instead of the 10 of the compiler's IEEE divide.
+DE_DEV float de_rcp_nr(float b) {
+    float y = __builtin_amdgcn_rcpf(b);
+    float e = de_fma(-b, y, 1.0f);
+    return de_fma(e, y, y);
+}
+
 #define DE_PI 0x1.921fb6p+1f
 #define DE_PIO2 0x1.921fb6p+0f
 #define DE_LN2_HI 0x1.63p-1f

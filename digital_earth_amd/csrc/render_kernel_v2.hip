@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                         if (peri2 > K * K) { tap_escaped = true; tap_do = false; }
                     }
                     if (tap_do) {
-                        const float inv_len = 1.0f / tap_len;          // one real divide, three 5-operation quotients (de_div_y)
+                        const float inv_len = de_rcp_nr(tap_len);      // RN(1 / len) in 3 operations, then three 5-operation quotients (de_div_y)
                         const vec3 n = v3(de_div_y(Q.x, tap_len, inv_len), de_div_y(Q.y, tap_len, inv_len), de_div_y(Q.z, tap_len, inv_len));
                         if (MODE) wk.taps_r8++;
                         TexR8 T = a.topo;   // per-lane map select (two maps only in this class)

@@ -256,6 +256,19 @@ def test_fast_sqrt_is_correctly_rounded(Renderer):
     assert r.debug_math(9, np.array([0.0], np.float32))[0] == 0.0
 
 
+def test_fast_reciprocal_is_correctly_rounded(Renderer):
+    """de_rcp_nr (v_rcp_f32 + one Newton step) == 1 / x (IEEE) for EVERY significand, at several exponents."""
+    r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
+    m = np.arange(1 << 23, dtype=np.uint32)
+    one = np.ones(1 << 23, np.float32)
+    for expo in (127, 126, 149, 150, 100, 180):       # [1,2), [0.5,1), |position| ~ 6.4e6 m, small, large
+        x = ((np.uint32(expo) << np.uint32(23)) | m).view(np.float32)
+        got = r.debug_math(13, x)
+        want = r.debug_math(7, one, x)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), expo
+        assert (want == (1.0 / x.astype(np.float64)).astype(np.float32)).all()
+
+
 def test_log_of_a_random_draw(Renderer):
     """de_log_unit == de_log on every value rng_next can return (k * 2^-24, k = 0 .. 2^24 - 1)."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
