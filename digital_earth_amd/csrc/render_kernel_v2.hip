@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     const FrameConsts& fc = *a.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
     const bool same_dims = (a.clouds.w == a.topo.w) && (a.clouds.h == a.topo.h);
+    // frame constants of the hot loops, read once (left as fc.x they are re-loaded from memory, with a wait, on every trip)
+    const float land_height_scale = fc.land_height_scale, normal_eps = fc.normal_eps;
+    const float escape_r = DE_PLANET_R + de_max(land_height_scale, 0.0f) + 8100.0f;
 
     Work2 wk = {0, 0, 0, 0, 0, 0};
     uint32_t n_samples = 0, path_vertices = 0;
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 } else if (state <= S_ST_S) {
                     Q = P + W * t;
                 } else {
-                    const float e = fc.normal_eps;
+                    const float e = normal_eps;
                     Q = P;
                     if (state == S_NRM1) Q = P - v3(e, 0.0f, 0.0f);
                     if (state == S_NRM2) Q = P - v3(0.0f, e, 0.0f);
@@ -331,7 +334,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     // cnt <= 100.  The result is -1 whatever the steps in between: skip them.
                     if (state <= S_ST_S && cnt <= 100) {
                         const float b = dot(Q, W);
-                        const float K = DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f;
+                        const float K = escape_r;
                         const float peri2 = (b < 0.0f) ? (tap_len * tap_len - b * b) : tap_len * tap_len;
                         if (peri2 > K * K) { tap_escaped = true; tap_do = false; }
                     }
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                             else state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
                         }
                     } else {
-                        float sdf = len - DE_PLANET_R - fc.land_height_scale * tex;
+                        float sdf = len - DE_PLANET_R - land_height_scale * tex;
                         if (state <= S_ST_S && tap_escaped) {
                             t = MAX_RAY_DIST;                              // "ray_dist < max_ray_dist" fails -> -1
                             after_sphere_trace(state == S_ST_P);
