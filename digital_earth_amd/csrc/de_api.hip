@@ -296,8 +296,8 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
         const unsigned max_waves = (unsigned)c->n_cus * waves_per_cu;
         const unsigned n_waves = (unsigned)a.n_tiles > max_waves ? max_waves : (unsigned)a.n_tiles;
         dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
-        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a);
-        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a);
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
+        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
         if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
         return;
     }

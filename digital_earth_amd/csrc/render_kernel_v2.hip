@@ -161,7 +161,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 
 // MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
 template <bool CLAMP, int MODE>
-__global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a) {
+__global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a, const FrameConsts* __restrict__ fcp) {
     using namespace v2;
     // Persistent waves over WORK ITEMS = single samples.  Item w of the launch is sample (w / 64) % spp of lane-pixel
     // (w & 63) of owned tile a.tiles[w / (64 * spp)].  A wave takes chunks of DE_V2_CHUNK consecutive items from a
@@ -175,7 +175,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     const uint32_t total_items = (uint32_t)a.n_tiles * items_per_tile;
     uint32_t w_lo = 0, w_hi = 0;          // wave-uniform: this wave's current chunk [w_lo, w_hi)
     uint32_t w = 0;                       // this lane's current item
-    const FrameConsts& fc = *a.fc;
+    // the frame constants come through a top-level `const __restrict__` kernel argument: the compiler then knows that no
+    // store of this kernel can change them and reads them with scalar loads (as a member of RenderArgs they were
+    // re-read with vector loads, each with its own wait, all through the transition code)
+    const FrameConsts& fc = *fcp;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
     const bool same_dims = (a.clouds.w == a.topo.w) && (a.clouds.h == a.topo.h);
     // frame constants of the hot loops, read once (left as fc.x they are re-loaded from memory, with a wait, on every trip)
