@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     } else { maxv = maxr; rmaxv = rmaxr; }
                     const float neg_log = -de_log_unit(rng_next(rng));
                     float t_step = de_div_rc_pinf(neg_log, maxv, rmaxv);
-                    if (any_slow_div) { if (rmaxv == 0.0f) t_step = neg_log / maxv; }
+                    // (the empty asm keeps this a branch: without it the compiler evaluates the divide on every trip and selects)
+                    if (any_slow_div) { asm volatile("" ::: "memory"); if (rmaxv == 0.0f) t_step = neg_log / maxv; }
                     C = C + t_step * W;
                     t += t_step;
                     if (MODE) wk.tracking_steps++;
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 // numerators: sums of extinction x density, >= 1e-20 inside the atmosphere (Rayleigh density >= 2e-15 up to 110 km)
                 auto gas_div = [&](float x) -> float {
                     float q = de_div_rc_ng(x, maxr, rmaxr);
-                    if (any_slow_div) { if (rmaxr == 0.0f) q = x / maxr; }
+                    if (any_slow_div) { asm volatile("" ::: "memory"); if (rmaxr == 0.0f) q = x / maxr; }
                     return q;
                 };
                 if (!tap_alive) {                                  // t >= t_max: the segment ends without an event
