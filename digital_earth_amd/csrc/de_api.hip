@@ -269,7 +269,7 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
-    a->pend_thr = 20; a->heavy_thr = 14; a->tune_b = 32; a->gas_thr = 10;
+    a->pend_thr = 18; a->heavy_thr = 13; a->tune_b = 24; a->gas_thr = 10;
     if (const char* e = getenv("DE_V2_G")) a->gas_thr = atoi(e);
     a->chunk = 64;
     if (const char* e = getenv("DE_V2_CHUNK")) { int v = atoi(e); if (v >= 1) a->chunk = v; }
