@@ -401,6 +401,7 @@ __global__ void math_kernel(int fn, const float* a, const float* b, float* out, 
         case 11: r = de_div_y(x, y, 1.0f / y); break;
         case 12: r = de_log_unit(x); break;
         case 13: r = de_rcp_nr(x); break;
+        case 14: r = de_exp_nonpos(x); break;
         default: r = 0.0f;
     }
     out[k] = r;

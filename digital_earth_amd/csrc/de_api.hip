@@ -629,7 +629,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
 }
 
 int de_debug_math(de_ctx* c, int fn, const float* a, const float* b, float* out, uint64_t n) {
-    if (!c || !a || !out || fn < 0 || fn > 13) return fail(DE_ERR_INVALID, "bad arguments");
+    if (!c || !a || !out || fn < 0 || fn > 14) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     float *da = nullptr, *db = nullptr, *dout = nullptr;
     HIP_TRY(hipMalloc(&da, n * sizeof(float)));

@@ -363,15 +363,15 @@ DE_DEV float get_ozone_density(float h) {                                       
     float h_km = h * 0.001f;
     float rel = h_km - (float)(25000.0 * 0.001);
     rel = rel * rel;
-    float d = (float)(1.0 - 0.375) * de_exp(DE_DIVC_NG(-rel, 49.0f));
-    d += 0.375f * de_exp(-rel / 256.0f);
+    float d = (float)(1.0 - 0.375) * de_exp_nonpos(DE_DIVC_NG(-rel, 49.0f));
+    d += 0.375f * de_exp_nonpos(-rel / 256.0f);
     float t = h_km - 15.0f;
     d += de_max(0.0f, -0.000015f * (t * t * t));
     return d;
 }
 DE_DEV float get_rayl_density(float h) {                                                               // :249-253
     float t = h + 24239.99f;
-    return DE_DIVC_NG(3.68082f * de_exp(DE_DIVC_NG(-(t * t), 532307548.4168f)), 1.225f);
+    return DE_DIVC_NG(3.68082f * de_exp_nonpos(DE_DIVC_NG(-(t * t), 532307548.4168f)), 1.225f);
 }
 // :255-268.  The reference's four-way branch, with the three exponential branches folded into ONE exp call on
 // per-lane selected (offset, scale, coefficient, addend): a wave whose lanes sit in different altitude bands would
@@ -383,7 +383,7 @@ DE_DEV float get_mie_density(float h) {
     const float coef = bA ? 0.0918f : (bB ? 0.3000f : 0.6500f);
     const float add = bA ? 0.0f : (bB ? -0.092f : 0.18899f);
     float t = h + off;
-    float e = de_exp(k * (t * t));
+    float e = de_exp_nonpos(k * (t * t));
     float dens = coef * e + add;
     float lin = 1.0f - DE_DIVC_NG(h, 8136.646f);
     dens = bC ? dens : lin;

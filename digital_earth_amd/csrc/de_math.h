@@ -119,6 +119,25 @@ DE_DEV float de_exp(float x) {
     return (x != x) ? x : res;
 }
 
+// de_exp for an argument that is <= 0 or NaN (the negated squares of the density profiles): the overflow select of
+// de_exp cannot fire and is left out; every other operation is de_exp's.
+DE_DEV float de_exp_nonpos(float x) {
+    float n = de_floor(de_fma(x, DE_LOG2E, 0.5f));
+    float r = de_fma(-n, DE_LN2_HI, x);
+    r = de_fma(-n, DE_LN2_LO, r);
+    float q = 0x1.6b9e2p-10f;
+    q = de_fma(q, r, 0x1.1239bep-7f);
+    q = de_fma(q, r, 0x1.5556d6p-5f);
+    q = de_fma(q, r, 0x1.555492p-3f);
+    q = de_fma(q, r, 0x1.fffffep-2f);
+    float p = de_fma(r * r, q, r);
+    p = p + 1.0f;
+    int ni = (int)n;
+    float res = p * de_u2f((uint32_t)(ni + 127) << 23);
+    res = (x < -87.0f) ? 0.0f : res;
+    return (x != x) ? x : res;
+}
+
 // natural log: 0 -> -inf, x < 0 -> NaN, +inf -> +inf; subnormals scaled first
 DE_DEV float de_log(float x) {
     float xs = x;

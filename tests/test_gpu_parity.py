@@ -269,6 +269,18 @@ def test_fast_reciprocal_is_correctly_rounded(Renderer):
         assert (want == (1.0 / x.astype(np.float64)).astype(np.float32)).all()
 
 
+def test_exp_of_a_non_positive_argument(Renderer):
+    """de_exp_nonpos == de_exp on arguments <= 0 (dense sample down to underflow, -0, -inf) and on NaN."""
+    r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
+    rng = np.random.default_rng(3)
+    x = np.concatenate([-np.abs(rng.standard_normal(1 << 22)).astype(np.float32) * np.float32(40.0),
+                        -np.linspace(0.0, 120.0, 1 << 20, dtype=np.float32),
+                        np.array([0.0, -0.0, -np.inf, np.nan, -87.0, -87.00001, -1e-30], np.float32)])
+    a, b = r.debug_math(14, x), r.debug_math(0, x)
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all()
+
+
 def test_log_of_a_random_draw(Renderer):
     """de_log_unit == de_log on every value rng_next can return (k * 2^-24, k = 0 .. 2^24 - 1)."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
