@@ -269,12 +269,12 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
 
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = (MODE == 1) ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t st_batches = 0, st_batch_lanes = 0, st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
+    int n_wait = 0;
     for (;;) {
         const bool tapL = is_tap(state), gasL = is_gas(state);
         const unsigned long long m_tap = __ballot(tapL), m_gas = __ballot(gasL);
-        const unsigned long long m_live = __ballot(state != S_DONE || stash != 0);
-        if (m_live == 0ull) break;
         if (MODE == 1) {
+            const unsigned long long m_live = __ballot(state != S_DONE || stash != 0);
             st_trips++; st_tap_lanes += __popcll(m_tap); st_gas_lanes += __popcll(m_gas);
             st_tap_trips += (m_tap != 0ull); st_gas_trips += (m_gas != 0ull);
             st_done_lanes += 64 - __popcll(m_live);
@@ -479,10 +479,11 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         const bool pendL = (state >= S_AFTER_ST_P && state != S_DONE && !parked) || (state == S_DONE && stash == 4);
         const int n_pend = __popcll(__ballot(pendL));
         const int n_loop = __popcll(__ballot(is_tap(state) || is_gas(state)));
-        const int n_w1 = __popcll(__ballot(stash == 1)), n_w2 = __popcll(__ballot(stash == 2)), n_w3 = __popcll(__ballot(stash == 3));
         const bool flush_all = n_loop < a.tune_b;                        // too few lanes iterating: process everything that waits
-        const bool batch_due = (n_w1 >= a.heavy_thr) || (n_w2 >= a.heavy_thr) || (n_w3 >= a.heavy_thr);
-        if (!(n_pend >= a.pend_thr || batch_due || (flush_all && (n_pend > 0 || n_w1 + n_w2 + n_w3 > 0)))) continue;
+        // n_wait: stashed paths waiting for a batch.  The stash changes only inside a pass, and a pass runs every batch that
+        // has reached a.heavy_thr, so between passes no batch is due and the count taken at the end of the last pass holds.
+        if (n_loop == 0 && n_pend == 0 && n_wait == 0) break;            // every lane is S_DONE with an empty stash
+        if (!(n_pend >= a.pend_thr || (flush_all && (n_pend > 0 || n_wait > 0)))) continue;
         if (MODE == 1) { st_passes++; st_pend_lanes += n_pend; }
 
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
@@ -743,6 +744,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 state = S_ST_P;
             }
         }
+        n_wait = __popcll(__ballot(stash >= 1 && stash <= 3));
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[7] += now_ - tlast; tlast = now_; }
     }
 
