@@ -220,8 +220,12 @@ int run_setup(de_ctx* c) {
     hipLaunchKernelGGL(setup_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, s);
     HIP_TRY(hipGetLastError());
     // prove (exhaustively, on the device) for which wavelength nodes the 3-operation division by the majorant is exact
-    HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
+    if (c->p.flags & DE_FLAG_NO_FAST_DIVISION) {      // test hook: every node "fails" the proof
+        HIP_TRY(hipMemsetAsync(c->d_div_fail, 0xFF, DE_N_NODES * sizeof(unsigned int), c->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
+    }
     hipLaunchKernelGGL(enable_fast_div_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, c->d_nodes, (const unsigned int*)c->d_div_fail);
     HIP_TRY(hipGetLastError());
     c->params_dirty = false;

@@ -48,7 +48,8 @@ enum {
     DE_FLAG_FIXED_WAVELENGTH = 1u << 0, /* BASELINE cfg1: skip spectrum_sample's draw, use fixed_wavelength */
     DE_FLAG_CLAMP_SAMPLER = 1u << 1,    /* CLAMP_TO_EDGE instead of REPEAT texture addressing */
     DE_FLAG_RAY_MARCHER = 1u << 2,      /* integrate with ray_marcher (pathtracer.py:544-685) instead of path_tracer */
-    DE_FLAG_AGX = 1u << 3               /* display with srgb_transfer(AgX(linear)) — the alternative at renderer.py:356 (lib/AgX.py) — instead of OpenDRT + CRF + gamma */
+    DE_FLAG_AGX = 1u << 3,              /* display with srgb_transfer(AgX(linear)) — the alternative at renderer.py:356 (lib/AgX.py) — instead of OpenDRT + CRF + gamma */
+    DE_FLAG_NO_FAST_DIVISION = 1u << 4  /* test hook: treat every wavelength as one whose 3-operation division is NOT proven exact, so the kernels take their IEEE-divide fallback; results must not change */
 };
 
 /* Scalar state of the reference Renderer (renderer.py:18-58), set through its set_* kernels (:224-266). */

@@ -256,6 +256,24 @@ def test_fast_sqrt_is_correctly_rounded(Renderer):
     assert r.debug_math(9, np.array([0.0], np.float32))[0] == 0.0
 
 
+def test_ieee_divide_fallback_gives_the_same_frame(Renderer, lut_arrays):
+    """The kernels divide by a wavelength's majorant in 3 operations only where that is proven exact on the device; the
+    fallback (IEEE divide, behind never-taken branches with the shipped LUTs) is forced here and must give the same bits."""
+    from digital_earth_amd import _native
+    def configure(r):
+        r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, True)
+    r, o = _render_pair(Renderer, lut_arrays, 128, 72, 2, configure, dict(texture_source="synthetic", texture_size=(2048, 1024)))
+    g, c, err, same = _compare(r, o, 2)
+    assert same == 1.0
+    r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, False)
+    r.reset_framebuffer(); r.accumulate(2)
+    assert (r.fetch_hdr().view(np.uint32) == g.view(np.uint32)).all()
+    for v in (1, 2):                                   # both kernel variants have the fallback
+        r.set_kernel_variant(v); r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, True)
+        r.reset_framebuffer(); r.accumulate(2)
+        assert (r.fetch_hdr().view(np.uint32) == g.view(np.uint32)).all()
+
+
 def test_fast_reciprocal_is_correctly_rounded(Renderer):
     """de_rcp_nr (v_rcp_f32 + one Newton step) == 1 / x (IEEE) for EVERY significand, at several exponents."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
