@@ -275,7 +275,7 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
     a->pend_thr = 18; a->heavy_thr = 13; a->tune_b = 24; a->gas_thr = 10;
     if (const char* e = getenv("DE_V2_G")) a->gas_thr = atoi(e);
-    a->chunk = 64;
+    a->chunk = 128;
     if (const char* e = getenv("DE_V2_CHUNK")) { int v = atoi(e); if (v >= 1) a->chunk = v; }
     if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
     if (const char* e = getenv("DE_V2_A")) a->heavy_thr = atoi(e);
