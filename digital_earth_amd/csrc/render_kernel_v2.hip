@@ -143,7 +143,7 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 }  // namespace v2
 
 #ifndef DE_V2_CHUNK
-#define DE_V2_CHUNK 64            // default work items a wave takes from the device-wide counter per atomic (RenderArgs::chunk)
+#define DE_V2_CHUNK 128           // default work items a wave takes from the device-wide counter per atomic (RenderArgs::chunk, set by the host)
 #endif
 #define DE_V2_STASH_FIELDS 36
 #ifndef DE_V2_BLOCK
