@@ -158,6 +158,7 @@ struct de_ctx {
     float* d_hdr_own = nullptr;
     float* d_image = nullptr;    // (W, H, 3)
     float* d_scratch = nullptr;  // (W, H, 3) / debug [H][W][4]
+    float* h_stage = nullptr;     // pinned host staging for fetch_image / fetch_hdr (a pageable destination copies at a fraction of the link rate)
     uint32_t* d_tiles = nullptr;
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;
@@ -311,6 +312,21 @@ void launch_render(de_ctx* c, const RenderArgs& a) {
     else hipLaunchKernelGGL((render_kernel<true, true, MODE>), grid, block, 0, c->stream, a);
 }
 
+// device (W*H*3 floats) -> caller's buffer through the pinned staging buffer
+int copy_out(de_ctx* c, float* out, const float* d_src) {
+    const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
+    if (!c->h_stage && hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) c->h_stage = nullptr;
+    if (c->h_stage) {
+        HIP_TRY(hipMemcpyAsync(c->h_stage, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(out, c->h_stage, bytes);
+    } else {
+        HIP_TRY(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return DE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,6 +389,7 @@ int de_destroy(de_ctx* c) {
     for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_div_fail};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_stage) hipHostFree(c->h_stage);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -524,9 +541,7 @@ int de_fetch_image(de_ctx* c, float* out) {
     if (!out) return fail(DE_ERR_INVALID, "out is null");
     int rc = de_render_to_image(c, nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->d_image, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return DE_OK;
+    return copy_out(c, out, c->d_image);
 }
 
 int de_fetch_hdr(de_ctx* c, float* out) {
@@ -535,9 +550,7 @@ int de_fetch_hdr(de_ctx* c, float* out) {
     size_t npx = (size_t)c->W * c->H;
     hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, c->d_scratch, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return DE_OK;
+    return copy_out(c, out, c->d_scratch);
 }
 
 int de_upload_hdr(de_ctx* c, const float* hdr, int spp) {
