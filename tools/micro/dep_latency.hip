@@ -30,6 +30,6 @@ void run(float* out, int waves_per_simd) {
 }
 int main() {
     float* out; hipMalloc(&out, 256 * 4 * 8 * 64 * 4);
-    for (int w = 1; w <= 4; ++w) { run<1>(out, w); run<2>(out, w); run<4>(out, w); run<8>(out, w); }
+    for (int w = 1; w <= 8; ++w) { run<1>(out, w); run<4>(out, w); }
     return 0;
 }
