@@ -16,6 +16,7 @@
 
 namespace {
 
+#define DE_N_COUNTERS 64   // 0-6 work counters, 7-8 trips / passes, 16-47 scheduler statistics, 48-59 section timers (render_kernel_v2 MODE 1)
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
@@ -364,7 +365,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_fc, sizeof(FrameConsts));
     if (e == hipSuccess) e = hipMalloc(&c->d_nodes, DE_N_NODES * sizeof(LambdaNode));
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_counters, DE_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_div_fail, DE_N_NODES * sizeof(unsigned int));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -372,7 +373,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_o3, 441 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_hdr, 0, npx * 3 * sizeof(float), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) {
         std::string msg = std::string("de_create: ") + hipGetErrorString(e);
         de_destroy(c);
@@ -480,7 +481,7 @@ int de_reset(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->d_hdr, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream));
     memset(&c->counters, 0, sizeof(c->counters));
     c->current_spp = 0;
     return DE_OK;
@@ -623,6 +624,16 @@ int de_get_counters(de_ctx* c, de_counters* out) {
     out->samples = h[0]; out->taps_r8 = h[1]; out->taps_rgb8 = h[2]; out->sphere_steps = h[3];
     out->tracking_steps = h[4]; out->vertices = h[5]; out->rng_draws = h[6];
     for (int i = 0; i < 9; ++i) out->reserved[i] = h[7 + i];   // scheduler statistics of render_kernel_v2 (see its MODE 1 epilogue)
+    return DE_OK;
+}
+
+int de_debug_sched_stats(de_ctx* c, uint64_t* out, int n) {
+    if (!c || !out || n < 0 || n > DE_N_COUNTERS - 16) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long h[DE_N_COUNTERS];
+    HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) out[i] = h[16 + i];
     return DE_OK;
 }
 

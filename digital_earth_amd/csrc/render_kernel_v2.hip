@@ -267,18 +267,24 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         else { trg = 1.0f; enter_cloud(2); }
     };
 
-    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = (MODE == 1) ? __builtin_amdgcn_s_memtime() : 0ull;
-    uint32_t st_batches = 0, st_batch_lanes = 0, st_done_lanes = 0, st_surf_wait = 0, st_trips = 0, st_passes = 0, st_tap_lanes = 0, st_gas_lanes = 0, st_pend_lanes = 0, st_tap_trips = 0, st_gas_trips = 0;
+    // MODE 1: per-wave scheduler statistics (de_debug_sched_stats; indices documented in tools/sched_stats.py)
+    unsigned long long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tlast = (MODE == 1) ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t st[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) st[i] = 0;
+#define DE_ST(i, v) { if (MODE == 1) st[i] += (uint32_t)(v); }
+#define DE_ST_RUN(i, pred) { if (MODE == 1) { st[i] += 1u; st[(i) + 1] += (uint32_t)__popcll(__ballot(pred)); } }
     int n_wait = 0;
     for (;;) {
         const bool tapL = is_tap(state), gasL = is_gas(state);
         const unsigned long long m_tap = __ballot(tapL), m_gas = __ballot(gasL);
         if (MODE == 1) {
             const unsigned long long m_live = __ballot(state != S_DONE || stash != 0);
-            st_trips++; st_tap_lanes += __popcll(m_tap); st_gas_lanes += __popcll(m_gas);
-            st_tap_trips += (m_tap != 0ull); st_gas_trips += (m_gas != 0ull);
-            st_done_lanes += 64 - __popcll(m_live);
-            st_surf_wait += __popcll(__ballot(state == S_SURF_FINISH || state == S_SURF_SETUP));
+            st[0]++; st[2] += __popcll(m_tap); st[3] += __popcll(m_gas);
+            st[4] += (m_tap != 0ull);
+            st[29] += 64 - __popcll(m_live);
+            st[30] += __popcll(__ballot(state >= S_SC_FINISH && state <= S_SURF_FINISH && stash >= 1 && stash <= 3));
+            st[31] += __popcll(__ballot(state >= S_AFTER_ST_P && state != S_DONE));
         }
 
         if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
@@ -297,6 +303,8 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         // otherwise (never with the shipped LUTs) the wave takes the branch with the real divide
         const bool any_slow_div = run_gas && (__ballot(gasR && rmaxr == 0.0f) != 0ull);
         if (m_tap != 0ull || run_gas) {
+            DE_ST_RUN(7, tapL || gasR)
+            if (run_gas) DE_ST_RUN(5, gasR)
             if (tapL || gasR) {
                 const bool cloud = is_cloud_tap(state);
                 const bool track = cloud || gasR;
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
             }
         }
 
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[1] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[3] += now_ - tlast; tlast = now_; }
         // ============================================================ transitions
         const bool heavyA = (state >= S_SC_FINISH && state <= S_SURF_FINISH);
         const bool parked = heavyA && stash >= 1 && stash <= 3;          // both of the lane's paths wait for a batch
@@ -484,11 +492,12 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         // has reached a.heavy_thr, so between passes no batch is due and the count taken at the end of the last pass holds.
         if (n_loop == 0 && n_pend == 0 && n_wait == 0) break;            // every lane is S_DONE with an empty stash
         if (!(n_pend >= a.pend_thr || (flush_all && (n_pend > 0 || n_wait > 0)))) continue;
-        if (MODE == 1) { st_passes++; st_pend_lanes += n_pend; }
+        if (MODE == 1) { st[1]++; st[10] += n_pend; }
 
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[0] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[4] += now_ - tlast; tlast = now_; }
         // ---- event resolution, light sample, branch (pathtracer.py:200-205, 369-375, 404, 441-444)
         if (__ballot(state == S_AFTER_DT_C) != 0ull) {
+            DE_ST_RUN(11, state == S_AFTER_DT_C)
             if (state == S_AFTER_DT_C) {
                 const int cloud_event = rmo_event >> 4;
                 const int gas_event = rmo_event & 15;
@@ -534,9 +543,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
             }
         }
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[3] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[5] += now_ - tlast; tlast = now_; }
         // ---- end of path: miss epilogue, NaN guard, colour accumulation (pathtracer.py:455-469, renderer.py:329-330)
         if (__ballot(state == S_END || state == S_END_MISS) != 0ull) {
+            DE_ST_RUN(13, state == S_END || state == S_END_MISS)
             if (state == S_END || state == S_END_MISS) {
                 const LambdaNode& L = a.nodes[node];
                 if (state == S_END_MISS) {
@@ -560,9 +570,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 state = S_NEW;
             }
         }
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[4] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[6] += now_ - tlast; tlast = now_; }
         // ---- a path reached an expensive transition: put it aside (or swap with the lane's resumable path)
         if (__ballot(state >= S_SC_FINISH && state <= S_SURF_FINISH) != 0ull) {
+            DE_ST_RUN(15, state >= S_SC_FINISH && state <= S_SURF_FINISH && (stash == 0 || stash == 4))
             if (state >= S_SC_FINISH && state <= S_SURF_FINISH && (stash == 0 || stash == 4)) {
                 const int kind = state - S_SC_FINISH + 1;
                 const bool resume = (stash == 4);
@@ -582,11 +593,11 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
             const bool run3 = c3 >= a.heavy_thr || (flush && c3 > 0);
             const bool in_batch = (stash == 1 && run1) || (stash == 2 && run2) || (stash == 3 && run3);
             if (run1 || run2 || run3) {
-                if (MODE == 1) { st_batches++; st_batch_lanes += __popcll(__ballot(in_batch)); }
                 if (in_batch) { DE_EXCHANGE_PATH() }  // stashed path in, current path out
                 const bool do1 = run1 && state == S_SC_FINISH, do2 = run2 && state == S_SURF_SETUP, do3 = run3 && state == S_SURF_FINISH;
                 // ---- volume vertex: in-scattering, phase sampling, roulette (pathtracer.py:394-401, 448-453)
                 if (__ballot(do1) != 0ull) {
+                    DE_ST_RUN(17, do1)
                     if (do1) {
                         const LambdaNode& L = a.nodes[node];
                         const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
@@ -608,6 +619,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
                 // ---- surface vertex, first half: normal, material, emissive, shadow-ray set-up (pathtracer.py:406-422)
                 if (__ballot(do2) != 0ull) {
+                    DE_ST_RUN(19, do2)
                     if (do2) {
                         const LambdaNode& L = a.nodes[node];
                         N = normalized(N);
@@ -641,6 +653,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
                 // ---- surface vertex, second half: direct light, bounce, roulette (pathtracer.py:431-439, 448-453)
                 if (__ballot(do3) != 0ull) {
+                    DE_ST_RUN(21, do3)
                     if (do3) {
                         const LambdaNode& L = a.nodes[node];
                         const float direct_tr = trg * trn;
@@ -667,9 +680,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 if (in_batch) { DE_EXCHANGE_PATH() stash = 4; }   // processed path back to the slot, resumable
             }
         }
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[5] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[7] += now_ - tlast; tlast = now_; }
         // ---- resume a processed path where the lane has nothing else to run
         if (__ballot(stash == 4 && (state == S_NEW || state == S_DONE || (state >= S_SC_FINISH && state <= S_SURF_FINISH))) != 0ull) {
+            DE_ST_RUN(23, stash == 4 && (state == S_NEW || state == S_DONE || (state >= S_SC_FINISH && state <= S_SURF_FINISH)))
             if (stash == 4 && (state == S_NEW || state == S_DONE)) {
                 DE_EXCHANGE_PATH()                    // the slot's content is dead afterwards
                 stash = 0;
@@ -681,9 +695,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 DE_RELOAD_NODE()
             }
         }
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[5] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[8] += now_ - tlast; tlast = now_; }
         // ---- next sample of this pixel (renderer.py:305-314)
         if (__ballot(state == S_NEW) != 0ull) {
+            DE_ST_RUN(25, state == S_NEW)
             // Hand out items of the wave's chunk; refill it (one device-wide atomic) when it runs dry.  Executed by ALL
             // lanes (wave-uniform branch) so that the chunk bounds w_lo / w_hi stay wave-uniform.
             const bool need = (state == S_NEW);
@@ -730,9 +745,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
             }
         }
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[6] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[9] += now_ - tlast; tlast = now_; }
         // ---- start of a vertex: intersect_land head (pathtracer.py:29-35)
         if (__ballot(state == S_VERTEX) != 0ull) {
+            DE_ST_RUN(27, state == S_VERTEX)
             if (state == S_VERTEX) {
                 if (MODE) { wk.vertices++; path_vertices++; }
                 vec2_ atmos = rsi(P, D, DE_ATMOS_UPPER);
@@ -745,7 +761,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
             }
         }
         n_wait = __popcll(__ballot(stash >= 1 && stash <= 3));
-        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[7] += now_ - tlast; tlast = now_; }
+        if (MODE == 1) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm[10] += now_ - tlast; tlast = now_; }
     }
 
     if (MODE == 1) {
@@ -757,9 +773,12 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         atomicAdd(&a.counters[5], (unsigned long long)wk.vertices);
         atomicAdd(&a.counters[6], (unsigned long long)wk.draws);
         if (lane == 0) {   // per-wave scheduler statistics: trips, passes, section cycle counters (s_memtime)
-            atomicAdd(&a.counters[7], (unsigned long long)st_trips);
-            atomicAdd(&a.counters[8], (unsigned long long)st_passes);
-            for (int i = 0; i < 7; ++i) atomicAdd(&a.counters[9 + i], tm[i] + (i == 6 ? tm[7] : 0ull));
+            atomicAdd(&a.counters[7], (unsigned long long)st[0]);
+            atomicAdd(&a.counters[8], (unsigned long long)st[1]);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) atomicAdd(&a.counters[16 + i], (unsigned long long)st[i]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) atomicAdd(&a.counters[48 + i], tm[i]);
         }
     }
 }

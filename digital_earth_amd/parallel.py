@@ -7,6 +7,11 @@ zero-initialised HDR buffer; one sum-reduce of that buffer to rank 0 per fetch a
 disjoint, so every pixel is x + 0 + ... + 0: exact).  The RNG stream of a sample depends only on
 (seed, absolute pixel, sample index), so the assembled frame is bit-identical to a 1-GPU render.
 
+Two ways to run the collective:
+  * `reduce_hdr` — torch.distributed on a torch-owned HDR tensor (default; what bench.py times);
+  * `LibraryComm` — the library's own RCCL communicator behind the C ABI (`de_comm_init` / `de_reduce`,
+    include/digital_earth.h), for hosts without PyTorch; only the 128-byte unique id has to travel between ranks.
+
 The functions take torch tensors on any device, which is how the world_size-2 gloo tests exercise them on CPU.
 """
 import numpy as np
@@ -33,16 +38,29 @@ def tiles_per_rank(width, height, world):
 
 def reduce_hdr(hdr, dst=0, group=None):
     """Sum the per-rank HDR buffers onto rank `dst` (in place).  One collective per fetch, not per sample:
-    24.9 MB at 1080p, 99.5 MB at 4K."""
+    24.9 MB at 1080p, 99.5 MB at 4K.
+
+    RCCL ("nccl") reduces the device tensor in place on the current stream.  gloo has no reduce for device tensors:
+    there the buffer is staged through host memory (the 2-ranks-on-one-GPU dry run and the CPU tests)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(hdr, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return hdr
+    if hdr.is_cuda and dist.get_backend(group) != "nccl":
+        host = hdr.cpu()                                   # synchronises the current stream
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            hdr.copy_(host)
+        return hdr
+    dist.reduce(hdr, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return hdr
 
 
 class DistributedFrame:
     """Binds a Renderer to this process's rank: torch owns the HDR buffer (so RCCL can reduce it in place) and the
-    renderer launches on torch's current stream (so the collective is ordered after the render kernel)."""
+    renderer launches on a torch stream (so the collective is ordered after the render kernel).
+
+    Lifetime: the Renderer is handed references to the tensor and the stream (`Renderer._bound`), so neither can be
+    collected while the context still points at them; `close()` gives the context back its own buffer and stream."""
 
     def __init__(self, renderer, rank, world, device_index, stream=None):
         import torch
@@ -54,14 +72,19 @@ class DistributedFrame:
         # overlaps the start of the next frame instead of idling the GPU.
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         W, H = renderer.image_res
-        self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            # allocated AND zero-filled on the frame's stream: every later reset / accumulate / reduce is enqueued on
+            # the same stream, so the fill is ordered before them (a fill on torch's default stream would not be)
+            self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
+        self.stream.synchronize()
         renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
         renderer.set_stream(self.stream.cuda_stream)
+        renderer._bound = (self.hdr, self.stream)
         renderer.set_tile_partition(rank, world)
 
     def render_frame(self, spp):
         """reset -> accumulate(spp) on this rank's tiles -> reduce to rank 0 -> display transform on rank 0 (device).
-        Everything is enqueued on this frame's stream; nothing here waits for the GPU."""
+        Everything is enqueued on this frame's stream; with RCCL nothing here waits for the GPU."""
         with self.torch.cuda.stream(self.stream):
             self.r.reset_framebuffer()        # zeroes the bound HDR buffer on the frame's stream
             self.r.accumulate(spp)
@@ -69,5 +92,48 @@ class DistributedFrame:
             if self.rank == 0:
                 self.r.render_to_image_device()
 
+    def fetch_hdr(self):
+        """The (reduced, on rank 0) HDR buffer as a (W, H, 3) array."""
+        return self.r.fetch_hdr()
+
     def synchronize(self):
         self.stream.synchronize()
+
+    def close(self):
+        if getattr(self, "r", None) is not None and getattr(self.r, "_bound", None) is not None:
+            self.stream.synchronize()
+            self.r.unbind()
+        self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LibraryComm:
+    """The library's own RCCL communicator (C ABI: de_comm_unique_id / de_comm_init / de_reduce / de_comm_destroy).
+
+    `exchange(id_bytes_or_None) -> id_bytes` is any host-side broadcast of the 128-byte unique id from rank 0
+    (a file, a socket, MPI, torch.distributed.broadcast_object_list ...): the only thing the host framework provides."""
+
+    def __init__(self, renderer, rank, world, exchange):
+        self.r = renderer
+        self.rank, self.world = rank, world
+        uid = renderer.comm_unique_id() if rank == 0 else None
+        uid = exchange(uid)
+        renderer.comm_init(uid, rank, world)
+        renderer.set_tile_partition(rank, world)
+
+    def render_frame(self, spp, root=0):
+        self.r.reset_framebuffer()
+        self.r.accumulate(spp)
+        self.r.reduce(root)
+        if self.rank == root:
+            self.r.render_to_image_device()
+
+    def close(self):
+        if self.r is not None:
+            self.r.comm_destroy()
+            self.r = None

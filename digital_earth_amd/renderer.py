@@ -359,6 +359,12 @@ class Renderer:
         check(self._lib.de_get_counters(self._h, ctypes.byref(c)))
         return c.as_dict()
 
+    def sched_stats(self, n=48):
+        """Raw scheduler statistics of render_kernel_v2 (counters must be enabled); see tools/sched_stats.py."""
+        out = (ctypes.c_uint64 * n)()
+        check(self._lib.de_debug_sched_stats(self._h, out, n))
+        return [int(x) for x in out]
+
     def hdr_device_pointer(self):
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         check(self._lib.de_hdr_device_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))

@@ -161,6 +161,10 @@ int de_set_kernel_variant(de_ctx* ctx, int variant);
  * 12 log of a random draw de_log_unit, 13 the 3-operation reciprocal de_rcp_nr,
  * 14 exp of a non-positive argument de_exp_nonpos), for bit-exact comparison against the oracle. */
 int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
+/* Scheduler statistics of render_kernel_v2 gathered while counters are enabled (sums over waves since de_reset):
+ * out[0..31] = lane / run counts per section, out[32..43] = shader cycles per section; n <= 48.  Index meaning:
+ * tools/sched_stats.py.  Profiling aid only. */
+int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 
 const char* de_last_error(void);

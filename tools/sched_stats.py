@@ -1,11 +1,79 @@
-import sys; sys.path.insert(0,'.')
-from digital_earth_amd.renderer import Renderer
-r = Renderer((1920,1080),(0,1,0),texture_source="synthetic")
-r.copy_textures(); r.enable_counters(True); import os; r.accumulate(int(os.environ.get("SPP","8"))); r.synchronize()
-c = r.counters(); s = c["sched"]; n=c["samples"]
-print(c)
-trips, passes = s[0], s[1]
-tm = s[2:9]; tot = sum(tm)
-names = ["loop head+trigger", "TAP body", "GAS body", "cheap transitions", "END", "stash+heavy batches", "NEW+VERTEX"]
-print("trips per sample-lane %.1f (ideal %.1f), passes/trip %.3f" % (trips*64/n, (c["sphere_steps"]+c["tracking_steps"])/n, passes/trips))
-for nm, x in zip(names, tm): print("  %-22s %5.1f %%  (%.0f cycles per trip)" % (nm, 100.0*x/tot, x/trips))
+#!/usr/bin/env python3
+"""Where render_kernel_v2 loses lanes: per-section runs, lanes per run and shader cycles (MODE 1 counters).
+
+  python tools/sched_stats.py [--preset "config - florida.txt"] [--spp 8] [--json out.json]
+
+Index of de_debug_sched_stats (render_kernel_v2.hip, DE_ST / DE_ST_RUN):
+  0 trips                 1 passes               2 lanes in the TAP class (sum over trips)   3 lanes in the GAS class
+  4 trips with TAP lanes  5 GAS runs, 6 lanes    7 first-half runs, 8 lanes                  10 pending lanes at passes
+  11/12 event resolution runs / lanes            13/14 END        15/16 stash put            17/18 19/20 21/22 heavy batches
+  23/24 resume            25/26 NEW              27/28 VERTEX     29 lanes with nothing left (sum over trips)
+  30 parked lanes (both paths wait for a batch)  31 lanes waiting for a pass
+  32.. shader cycles: head, first half, GAS body, TAP second half, trigger, event resolution, END, stash + batches,
+       resume, NEW, VERTEX
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from digital_earth_amd.renderer import Renderer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--preset", default=None)
+ap.add_argument("--spp", type=int, default=8)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--tex-quality", type=int, default=2)
+ap.add_argument("--json", default=None)
+args = ap.parse_args()
+
+r = Renderer((args.width, args.height), (0, 1, 0), texture_source="synthetic", texture_quality=args.tex_quality)
+if args.preset:
+    from digital_earth_amd.earth_viewer import load_config
+    load_config(args.preset).apply(r)
+r.copy_textures()
+r.enable_counters(True)
+r.accumulate(args.spp)
+r.synchronize()
+c = r.counters()
+s = r.sched_stats(48)
+n = max(c["samples"], 1)
+trips = max(s[0], 1)
+tm = s[32:44]
+tot = float(max(sum(tm), 1))
+print("samples %d  taps_r8/sample %.1f  sphere steps %.1f  tracking steps %.1f  vertices %.2f  draws %.1f" % (
+    n, c["taps_r8"] / n, c["sphere_steps"] / n, c["tracking_steps"] / n, c["vertices"] / n, c["rng_draws"] / n))
+print("trips %d (%.1f per sample-lane; ideal %.1f)  passes/trip %.3f" % (
+    s[0], s[0] * 64.0 / n, (c["sphere_steps"] + c["tracking_steps"]) / n, s[1] / trips))
+print("lanes per trip: TAP %.1f  GAS %.1f  waiting for a pass %.1f  parked %.1f  finished %.1f" % (
+    s[2] / trips, s[3] / trips, s[31] / trips, s[30] / trips, s[29] / trips))
+
+
+def run(name, i, cyc):
+    runs, lanes = s[i], s[i + 1]
+    print("  %-26s runs/trip %.3f  lanes/run %5.1f  cycles/run %7.0f  share of cycles %5.1f %%" % (
+        name, runs / trips, lanes / max(runs, 1), cyc / max(runs, 1), 100.0 * cyc / tot))
+
+
+run("first half (TAP + GAS)", 7, tm[1])
+run("GAS body", 5, tm[2])
+print("  %-26s runs/trip %.3f  lanes/run %5.1f  cycles/run %7.0f  share of cycles %5.1f %%" % (
+    "TAP second half", s[4] / trips, s[2] / max(s[4], 1), tm[3] / max(s[4], 1), 100.0 * tm[3] / tot))
+print("  %-26s                                   cycles/trip %6.0f  share of cycles %5.1f %%" % ("loop head + trigger", (tm[0] + tm[4]) / trips, 100.0 * (tm[0] + tm[4]) / tot))
+run("event resolution", 11, tm[5])
+run("END", 13, tm[6])
+run("stash put", 15, 0)
+for k, nm in enumerate(("batch: volume vertex", "batch: surface set-up", "batch: surface finish")):
+    run(nm, 17 + 2 * k, 0)
+print("  %-26s                                                    share of cycles %5.1f %%" % ("stash + batches (all)", 100.0 * tm[7] / tot))
+run("resume", 23, tm[8])
+run("NEW", 25, tm[9])
+run("VERTEX", 27, tm[10])
+print("pending lanes per pass %.1f" % (s[10] / max(s[1], 1)))
+if args.json:
+    with open(args.json, "w") as f:
+        json.dump({"counters": {k: v for k, v in c.items() if k != "sched"}, "sched": s, "args": vars(args),
+                   "ms": r.last_accumulate_ms()}, f)
+print("launch %.1f ms (MODE 1, instrumented)" % r.last_accumulate_ms())
