@@ -47,6 +47,7 @@ SYMBOLS = {
     "de_destroy": (ctypes.c_int, [_P]),
     "de_upload_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "de_generate_texture": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int]),
+    "de_share_textures": (ctypes.c_int, [_P, _P]),
     "de_download_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint64]),
     "de_texture_info": (ctypes.c_int, [_P, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3),
     "de_upload_luts": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int]),
@@ -63,6 +64,10 @@ SYMBOLS = {
     "de_hdr_device_ptr": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
     "de_bind_hdr": (ctypes.c_int, [_P, _P, ctypes.c_uint64]),
     "de_set_stream": (ctypes.c_int, [_P, _P]),
+    "de_comm_unique_id": (ctypes.c_int, [_P]),
+    "de_comm_init": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
+    "de_comm_destroy": (ctypes.c_int, [_P]),
+    "de_reduce": (ctypes.c_int, [_P, _P, ctypes.c_int]),
     "de_synchronize": (ctypes.c_int, [_P]),
     "de_last_accumulate_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(DeCounters)]),

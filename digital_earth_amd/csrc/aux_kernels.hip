@@ -23,7 +23,6 @@ __global__ void setup_kernel(SetupArgs s) {
         fc.fov = p.fov;
         fc.aspect_ratio = (float)((double)s.W / (double)s.H);          // renderer.py:19
         fc.aspect_scale = p.aspect_scale;
-        fc.inv_h_dummy = 0.0f;
         fc.sun_angular_radius = (float)(6.95e8 / 1.4959e11);           // renderer.py:297-299
         fc.sun_cos_angle = de_cos(fc.sun_angular_radius);              // :300
         float s_rot, c_rot, s_ang, c_ang;
@@ -55,7 +54,7 @@ __global__ void setup_kernel(SetupArgs s) {
         fc.drt_w = w / length(w);                                      // :370
         *s.fc = fc;
     }
-    if (n >= DE_N_NODES) return;
+    if (n >= DE_N_NODES || !s.do_nodes) return;
     // node n of the bisection tree: depth d = floor(log2 n), mid = (2*(n - 2^d) + 1) / 2^(d+1) — the same dyadic
     // value the reference reaches by mid = (lo + hi)/2 (exact in f32)
     float mid;

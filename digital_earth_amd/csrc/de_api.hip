@@ -2,6 +2,7 @@
 // (include/digital_earth.h).  No CPU fallback exists: every entry point needs a HIP device.
 #include "de_kernels.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,6 +34,7 @@ struct DevTexture {
     int tiles_x = 0, tiles_y = 0;
     int packed_clamp = -1;        // address mode the packed copy was built with
     bool set = false;
+    bool borrowed = false;        // the allocations belong to another context (de_share_textures)
 };
 
 uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -140,7 +142,9 @@ struct de_ctx {
     int device = 0;
     int W = 0, H = 0;
     de_params p;
-    bool params_dirty = true;
+    bool params_dirty = true;     // FrameConsts must be rebuilt (any scalar parameter, the topography width)
+    bool nodes_dirty = true;      // the wavelength table and its division proof must be rebuilt (LUTs, address mode, fixed wavelength)
+    int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 10, tune_chunk = 128, tune_wpc = 16, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -152,6 +156,7 @@ struct de_ctx {
     float* d_crf = nullptr;      // [n][1024][3]
     int n_crf = 0;
     bool luts_set = false;
+    bool luts_borrowed = false;
     FrameConsts* d_fc = nullptr;
     LambdaNode* d_nodes = nullptr;
     float* d_node_val = nullptr;
@@ -171,6 +176,8 @@ struct de_ctx {
     bool count = false;
     de_counters counters;
     int current_spp = 0;
+    void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
+    int comm_rank = 0, comm_world = 1;
     int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip)
 };
 
@@ -179,6 +186,7 @@ namespace {
 int ensure_packed(de_ctx* c, int slot, bool clamp) {
     DevTexture& t = c->tex[slot];
     if (t.packed_clamp == (clamp ? 1 : 0)) return DE_OK;
+    if (t.borrowed) return fail(DE_ERR_STATE, "a shared texture keeps its owner's address mode: set DE_FLAG_CLAMP_SAMPLER on the owner and render there once, then share again");
     if (t.ch == 1) {
         dim3 grid((unsigned)((t.w + 255) / 256), (unsigned)t.h);
         hipLaunchKernelGGL(pack_r8_kernel, grid, dim3(256), 0, c->stream, t.linear, t.packed, t.w, t.h, t.tiles_x, clamp ? 1 : 0);
@@ -193,8 +201,9 @@ int ensure_packed(de_ctx* c, int slot, bool clamp) {
 
 int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
     DevTexture& t = c->tex[slot];
-    if (t.linear) { hipFree(t.linear); t.linear = nullptr; }
-    if (t.packed) { hipFree(t.packed); t.packed = nullptr; }
+    if (t.linear && !t.borrowed) hipFree(t.linear);
+    if (t.packed && !t.borrowed) hipFree(t.packed);
+    t.linear = nullptr; t.packed = nullptr; t.borrowed = false;
     t.w = w; t.h = h; t.ch = ch; t.set = false; t.packed_clamp = -1;
     HIP_TRY(hipMalloc(&t.linear, (size_t)w * h * ch));
     if (ch == 1) {
@@ -208,7 +217,7 @@ int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
 }
 
 int run_setup(de_ctx* c) {
-    if (!c->params_dirty) return DE_OK;
+    if (!c->params_dirty && !c->nodes_dirty) return DE_OK;
     SetupArgs s;
     s.p = c->p;
     opendrt_consts(&s.drt[0], &s.drt[1], &s.drt[2], &s.drt[3], &s.drt[4], &s.drt[5]);
@@ -219,18 +228,23 @@ int run_setup(de_ctx* c) {
     s.cie.data = c->d_cie; s.cie.w = 441; s.cie.h = 2;
     s.srgb2spec = c->d_srgb2spec; s.o3 = c->d_o3;
     s.fc = c->d_fc; s.nodes = c->d_nodes; s.node_val = c->d_node_val;
-    hipLaunchKernelGGL(setup_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, s);
+    s.do_nodes = c->nodes_dirty ? 1 : 0;
+    // camera / sun / display changes rebuild the frame constants only (one wave); the 512-node wavelength table and the
+    // exhaustive division proof depend on the LUTs, the address mode and the fixed wavelength alone
+    hipLaunchKernelGGL(setup_kernel, dim3(c->nodes_dirty ? DE_N_NODES / 64 : 1), dim3(64), 0, c->stream, s);
     HIP_TRY(hipGetLastError());
-    // prove (exhaustively, on the device) for which wavelength nodes the 3-operation division by the majorant is exact
-    if (c->p.flags & DE_FLAG_NO_FAST_DIVISION) {      // test hook: every node "fails" the proof
-        HIP_TRY(hipMemsetAsync(c->d_div_fail, 0xFF, DE_N_NODES * sizeof(unsigned int), c->stream));
-    } else {
-        HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
+    if (c->nodes_dirty) {
+        // prove (exhaustively, on the device) for which wavelength nodes the 3-operation division by the majorant is exact
+        if (c->p.flags & DE_FLAG_NO_FAST_DIVISION) {      // test hook: every node "fails" the proof
+            HIP_TRY(hipMemsetAsync(c->d_div_fail, 0xFF, DE_N_NODES * sizeof(unsigned int), c->stream));
+        } else {
+            HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
+            hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
+        }
+        hipLaunchKernelGGL(enable_fast_div_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, c->d_nodes, (const unsigned int*)c->d_div_fail);
+        HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(enable_fast_div_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, c->d_nodes, (const unsigned int*)c->d_div_fail);
-    HIP_TRY(hipGetLastError());
-    c->params_dirty = false;
+    c->params_dirty = false; c->nodes_dirty = false;
     return DE_OK;
 }
 
@@ -275,42 +289,37 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
-    a->pend_thr = 18; a->heavy_thr = 13; a->tune_b = 24; a->gas_thr = 10;
-    if (const char* e = getenv("DE_V2_G")) a->gas_thr = atoi(e);
-    a->chunk = 128;
-    if (const char* e = getenv("DE_V2_CHUNK")) { int v = atoi(e); if (v >= 1) a->chunk = v; }
-    if (const char* e = getenv("DE_V2_THR")) a->pend_thr = atoi(e);
-    if (const char* e = getenv("DE_V2_A")) a->heavy_thr = atoi(e);
-    if (const char* e = getenv("DE_V2_B")) a->tune_b = atoi(e);
+    a->pend_thr = c->tune_pend; a->heavy_thr = c->tune_heavy; a->tune_b = c->tune_b; a->gas_thr = c->tune_gas; a->chunk = c->tune_chunk;
     return DE_OK;
 }
 
 template <int MODE>
-void launch_render(de_ctx* c, const RenderArgs& a) {
+hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
     if (!march && c->kernel_variant == 2) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
-        hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+        hipError_t me = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+        if (me != hipSuccess) return me;
         // waves: one per owned tile at most (a tile's first 64 work items), and no more than the CUs hold at 4 waves/SIMD
         // (more would only queue behind the resident ones and find the work counter exhausted; they would also keep the
         // small kernels of the other frame in flight — accumulate, display, memsets — waiting for a slot)
         const unsigned waves_per_block = DE_V2_BLOCK / 64;
-        unsigned waves_per_cu = 16u;
-        if (const char* e = getenv("DE_V2_WPC")) { int v = atoi(e); if (v >= 1) waves_per_cu = (unsigned)v; }
+        const unsigned waves_per_cu = (unsigned)c->tune_wpc;
         const unsigned max_waves = (unsigned)c->n_cus * waves_per_cu;
         const unsigned n_waves = (unsigned)a.n_tiles > max_waves ? max_waves : (unsigned)a.n_tiles;
         dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
         if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
         else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
         if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
-        return;
+        return hipGetLastError();
     }
     if (!clamp && !march) hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
     else if (clamp && !march) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
     else if (!clamp && march) hipLaunchKernelGGL((render_kernel<false, true, MODE>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((render_kernel<true, true, MODE>), grid, block, 0, c->stream, a);
+    return hipGetLastError();
 }
 
 // device (W*H*3 floats) -> caller's buffer through the pinned staging buffer
@@ -327,6 +336,48 @@ int copy_out(de_ctx* c, float* out, const float* d_src) {
     }
     return DE_OK;
 }
+
+
+// ---- RCCL, bound at run time (dlopen): a single-GPU user never loads it, and a process that already holds RCCL (PyTorch
+// ships its own copy) keeps ONE instance — the already-loaded library is preferred over a second load.
+struct UniqueId128;
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, struct UniqueId128, int) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct UniqueId128 { char internal[128]; };        // ncclUniqueId (rccl.h:43), passed BY VALUE to ncclCommInitRank
+Rccl g_rccl;
+int load_rccl() {
+    if (g_rccl.h) return DE_OK;
+    void* h = nullptr;
+    if (const char* e = getenv("DE_RCCL_PATH")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int pass = 0; pass < 2 && !h; ++pass)
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (h) break;
+        }
+    if (!h) return fail(DE_ERR_STATE, std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"));
+    Rccl r; r.h = h;
+    r.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, UniqueId128, int))dlsym(h, "ncclCommInitRank");
+    r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(h, "ncclReduce");
+    r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy || !r.GetErrorString)
+        return fail(DE_ERR_STATE, "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy / ncclGetErrorString");
+    g_rccl = r;
+    return DE_OK;
+}
+#define RCCL_TRY(expr)                                                                                           \
+    do {                                                                                                         \
+        int r_ = (expr);                                                                                         \
+        if (r_ != 0) return fail(DE_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));             \
+    } while (0)
 
 }  // namespace
 
@@ -352,6 +403,12 @@ int de_create(int device, int width, int height, de_ctx** out) {
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
     if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] == '1') c->kernel_variant = 1; }
+    {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
+        auto env_int = [](const char* name, int* v, int lo) { if (const char* e = getenv(name)) { int x = atoi(e); if (x >= lo) *v = x; } };
+        env_int("DE_V2_THR", &c->tune_pend, 0); env_int("DE_V2_A", &c->tune_heavy, 0); env_int("DE_V2_B", &c->tune_b, 0);
+        env_int("DE_V2_G", &c->tune_gas, 0); env_int("DE_V2_CHUNK", &c->tune_chunk, 1); env_int("DE_V2_WPC", &c->tune_wpc, 1);
+        env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
+    }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -387,7 +444,9 @@ int de_destroy(de_ctx* c) {
     if (!c) return DE_OK;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto& t : c->tex) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
+    if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
+    if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_div_fail};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -426,6 +485,34 @@ int de_generate_texture(de_ctx* c, int slot, int w, int h, uint32_t seed, int va
     return DE_OK;
 }
 
+int de_share_textures(de_ctx* dst, de_ctx* src) {
+    if (!dst || !src || dst == src) return fail(DE_ERR_INVALID, "two different contexts are needed");
+    if (dst->device != src->device) return fail(DE_ERR_INVALID, "contexts on different devices cannot share maps");
+    for (int i = 0; i < DE_TEX_COUNT; ++i)
+        if (!src->tex[i].set) return fail(DE_ERR_STATE, "the lending context must hold all 7 maps");
+    if (!src->luts_set) return fail(DE_ERR_STATE, "the lending context must hold the LUTs");
+    HIP_TRY(hipSetDevice(src->device));
+    // bring the lender's packed copies up to date for ITS address mode, then wait: the borrower reads them from another stream
+    const bool clamp = (src->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    for (int i = 0; i < DE_TEX_COUNT; ++i) { int rc = ensure_packed(src, i, clamp); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    for (int i = 0; i < DE_TEX_COUNT; ++i) {
+        DevTexture& t = dst->tex[i];
+        if (!t.borrowed) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
+        t = src->tex[i];
+        t.borrowed = true;
+    }
+    if (!dst->luts_borrowed) {
+        void* own[] = {dst->d_cie, dst->d_srgb2spec, dst->d_o3, dst->d_crf};
+        for (void* q : own) if (q) hipFree(q);
+    }
+    dst->d_cie = src->d_cie; dst->d_srgb2spec = src->d_srgb2spec; dst->d_o3 = src->d_o3; dst->d_crf = src->d_crf;
+    dst->n_crf = src->n_crf; dst->luts_set = true; dst->luts_borrowed = true;
+    dst->params_dirty = true; dst->nodes_dirty = true;
+    return DE_OK;
+}
+
 int de_download_texture(de_ctx* c, int slot, uint8_t* out, uint64_t out_bytes) {
     if (!c || slot < 0 || slot >= DE_TEX_COUNT || !out || !c->tex[slot].set) return fail(DE_ERR_INVALID, "texture not set");
     const DevTexture& t = c->tex[slot];
@@ -454,6 +541,12 @@ int de_upload_luts(de_ctx* c, const float* cie, const uint16_t* srgb2spec_f16, c
     for (int x = 0; x < 1024; ++x)
         for (int y = 0; y < n_crf; ++y)
             for (int ch = 0; ch < 3; ++ch) r[((size_t)y * 1024 + x) * 3 + ch] = crf[((size_t)x * n_crf + y) * 3 + ch];
+    if (c->luts_borrowed) {                  // stop borrowing: own copies again
+        c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; c->luts_borrowed = false;
+        HIP_TRY(hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_srgb2spec, 900 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_o3, 441 * sizeof(float)));
+    }
     if (c->d_crf) { hipFree(c->d_crf); c->d_crf = nullptr; }
     HIP_TRY(hipMalloc(&c->d_crf, r.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(c->d_cie, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -461,12 +554,13 @@ int de_upload_luts(de_ctx* c, const float* cie, const uint16_t* srgb2spec_f16, c
     HIP_TRY(hipMemcpyAsync(c->d_o3, o3, 441 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_crf, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n_crf = n_crf; c->luts_set = true; c->params_dirty = true;
+    c->n_crf = n_crf; c->luts_set = true; c->params_dirty = true; c->nodes_dirty = true;
     return DE_OK;
 }
 
 int de_set_params(de_ctx* c, const de_params* p) {
     if (!c || !p) return fail(DE_ERR_INVALID, "null argument");
+    if (p->flags != c->p.flags || memcmp(&p->fixed_wavelength, &c->p.fixed_wavelength, sizeof(float)) != 0) c->nodes_dirty = true;
     c->p = *p;
     c->params_dirty = true;
     return DE_OK;
@@ -496,11 +590,22 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     rc = fill_render_args(c, &a);
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.spp_begin = c->current_spp; a.spp_count = spp;
-    a.spp_magic = ((1ull << 40) / (unsigned long long)(spp > 0 ? spp : 1)) + 1ull;
-    {   // per-sample contribution buffer of render_kernel_v2 (8 B per sample of this rank's tiles; grows on demand)
-        const size_t need = (size_t)a.n_tiles * 64u * (size_t)(spp > 0 ? spp : 1);
-        if (need >= (size_t)1 << 32) return fail(DE_ERR_INVALID, "spp too large for one launch: split the call (n_tiles*64*spp must be < 2^32)");
+    const bool v2 = c->kernel_variant == 2 && !(c->p.flags & DE_FLAG_RAY_MARCHER);
+    // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
+    // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
+    // contribution buffer (kept <= 4 GB).  Larger requests are split here; the sample index continues from launch to launch
+    // and the per-pixel sum keeps sample order, so split launches give the same bits as one launch would.
+    int max_spp = spp > 0 ? spp : 1;
+    if (v2 && a.n_tiles > 0) {
+        const unsigned long long nt = (unsigned long long)a.n_tiles;
+        unsigned long long cap = ((1ull << 29) / (nt * 64ull));                          // 2^29 items = 4 GB of contributions
+        while (cap > 1 && nt * cap * cap >= (1ull << 40)) --cap;
+        if (cap < 1) cap = 1;
+        if (c->tune_max_spp > 0 && cap > (unsigned long long)c->tune_max_spp) cap = (unsigned long long)c->tune_max_spp;
+        if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
+        if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
+            return fail(DE_ERR_INVALID, "image too large for render_kernel_v2's 32-bit work-item index");
+        const size_t need = (size_t)a.n_tiles * 64u * (size_t)max_spp;
         if (need > c->contrib_items) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_contrib) hipFree(c->d_contrib);
@@ -508,12 +613,15 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             HIP_TRY(hipMalloc(&c->d_contrib, need * sizeof(uint2)));
             c->contrib_items = need;
         }
-        a.contrib = c->d_contrib;
     }
+    a.contrib = c->d_contrib;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (spp > 0 && a.n_tiles > 0) {
-        if (c->count) launch_render<1>(c, a); else launch_render<0>(c, a);
-        HIP_TRY(hipGetLastError());
+    for (int done = 0; done < spp && a.n_tiles > 0;) {
+        const int n = (spp - done < max_spp) ? spp - done : max_spp;
+        a.spp_begin = c->current_spp + done; a.spp_count = n;
+        a.spp_magic = ((1ull << 40) / (unsigned long long)n) + 1ull;
+        HIP_TRY(c->count ? launch_render<1>(c, a) : launch_render<0>(c, a));
+        done += n;
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timing_valid = true;
@@ -590,8 +698,13 @@ int de_set_stream(de_ctx* c, void* hip_stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = nullptr; c->own_stream = false;
+    if (!hip_stream) {                       // NULL: back to a stream of the context's own
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+        return DE_OK;
+    }
     c->stream = (hipStream_t)hip_stream;
-    c->own_stream = false;
     return DE_OK;
 }
 int de_synchronize(de_ctx* c) {
@@ -627,6 +740,51 @@ int de_get_counters(de_ctx* c, de_counters* out) {
     return DE_OK;
 }
 
+
+/* ---- in-library collective (SURVEY §8b `de_reduce`, §8e) */
+int de_comm_unique_id(void* out128) {
+    if (!out128) return fail(DE_ERR_INVALID, "out is null");
+    int rc = load_rccl();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(out128));
+    return DE_OK;
+}
+int de_comm_init(de_ctx* c, const void* id128, int rank, int world) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail(DE_ERR_INVALID, "bad communicator arguments");
+    if (c->comm) return fail(DE_ERR_STATE, "the context already has a communicator: de_comm_destroy first");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    UniqueId128 id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return DE_OK;
+}
+int de_comm_destroy(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    if (!c->comm) return DE_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    RCCL_TRY(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    return DE_OK;
+}
+int de_reduce(de_ctx* c, void* comm, int root) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    void* use = comm ? comm : c->comm;
+    if (!use) return fail(DE_ERR_STATE, "no communicator: pass an ncclComm_t or call de_comm_init");
+    if (root < 0 || (!comm && root >= c->comm_world)) return fail(DE_ERR_INVALID, "root out of range");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t count = (size_t)c->W * c->H * 3;
+    // in place: every rank's buffer is its own tiles plus zeros elsewhere; the root ends with the assembled frame
+    RCCL_TRY(g_rccl.Reduce(c->d_hdr, c->d_hdr, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, use, c->stream));
+    return DE_OK;
+}
+
 int de_debug_sched_stats(de_ctx* c, uint64_t* out, int n) {
     if (!c || !out || n < 0 || n > DE_N_COUNTERS - 16) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
@@ -649,8 +807,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     a.spp_begin = sample_index; a.spp_count = 1;
     a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
-    launch_render<2>(c, a);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_render<2>(c, a));
     HIP_TRY(hipMemcpyAsync(out, c->d_scratch, (size_t)c->W * c->H * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DE_OK;
@@ -659,17 +816,19 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
 int de_debug_math(de_ctx* c, int fn, const float* a, const float* b, float* out, uint64_t n) {
     if (!c || !a || !out || fn < 0 || fn > 14) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&da, n * sizeof(float)));
-    HIP_TRY(hipMalloc(&dout, n * sizeof(float)));
-    if (b) HIP_TRY(hipMalloc(&db, n * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(da, a, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (b) HIP_TRY(hipMemcpyAsync(db, b, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, da, db, dout, (size_t)n);
+    struct Bufs {   // freed on every exit path
+        float *da = nullptr, *db = nullptr, *dout = nullptr;
+        ~Bufs() { if (da) hipFree(da); if (db) hipFree(db); if (dout) hipFree(dout); }
+    } m;
+    HIP_TRY(hipMalloc(&m.da, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&m.dout, n * sizeof(float)));
+    if (b) HIP_TRY(hipMalloc(&m.db, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(m.da, a, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(m.db, b, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, m.da, m.db, m.dout, (size_t)n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, m.dout, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    hipFree(da); hipFree(dout); if (db) hipFree(db);
     return DE_OK;
 }
 

@@ -9,7 +9,6 @@
 struct FrameConsts {
     vec3 cam_pos, d, du, dv;                 // get_cast_dir basis            renderer.py:272,276-277
     float fov, aspect_ratio, aspect_scale;   //                               renderer.py:271-275
-    float inv_h_dummy;
     vec3 light_dir;                          //                               renderer.py:301-302
     vec3 sun_x, sun_y;                       // make_orthonormal_basis(light_dir), lib/math_utils.py:55-60 (same for every light sample)
     float sun_cos_angle, sun_angular_radius; //                               renderer.py:297-300
@@ -88,6 +87,7 @@ struct SetupArgs {
     FrameConsts* fc;
     LambdaNode* nodes;
     float* node_val;
+    int do_nodes;             // 0: frame constants only (camera / sun / display change)
 };
 
 struct DisplayArgs {

@@ -155,9 +155,6 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #ifndef DE_V2_MIN_WAVES
 #define DE_V2_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
-#ifndef DE_V2_PENDING_THRESHOLD
-#define DE_V2_PENDING_THRESHOLD 12   // run the transition pass when at least this many lanes wait for it
-#endif
 
 // MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
 template <bool CLAMP, int MODE>

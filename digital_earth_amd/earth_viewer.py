@@ -26,7 +26,10 @@ def np_normalize(v):           # lib/math_utils.py:78-80
     return v / np.sqrt(np.sum(v ** 2))
 
 
-def np_rotate_matrix(axis, theta):   # lib/math_utils.py:83-102 (Euler-Rodrigues, counter-clockwise about axis)
+def np_rotate_matrix(axis, theta):
+    """lib/math_utils.py:83-102 — rotation matrix for a counter-clockwise rotation about `axis` by `theta` radians
+    (Euler-Rodrigues formula).  The reference credits https://stackoverflow.com/a/6802723 for this helper; it is kept
+    because SURVEY §8(f)-1 asks for the reference's Camera math."""
     axis = np_normalize(axis)
     a = math.cos(theta / 2.0)
     b, c, d = -axis * math.sin(theta / 2.0)
@@ -100,6 +103,7 @@ class Camera:
         self._camera_pos = np.array((-15000000., 0.0, 15000000.))          # :27
         self._up = np_normalize(np.array(up, dtype=np.float64))
         self._last_mouse_pos = None
+        self._moved = False
 
     @property
     def mouse_exclusive_owner(self):
@@ -138,6 +142,7 @@ class Camera:
         out_dir_homo = np.array(list(out_dir) + [0.0])
         new_out_dir = np.matmul(np.matmul(roty, rotx), out_dir_homo)[:3]
         self._lookat_pos = self._camera_pos + new_out_dir
+        self._moved = True
         return True
 
     def move(self, direction, elapsed_time, shift=False):
@@ -152,16 +157,20 @@ class Camera:
         if self._compute_cam_r() < planet_r * 1.000:
             self._lookat_pos -= cam_step * 2
             self._camera_pos -= cam_step * 2
+        self._moved = True
         return True
 
     def update_camera(self, elapsed_time):
-        """No input devices on a headless node: nothing moves."""
-        return False
+        """earth_viewer.py:146-155: True when the camera changed since the last call.  No input devices on a headless node:
+        changes come from rotate() / move() / load()."""
+        moved, self._moved = self._moved, False
+        return moved
 
     def load(self, cfg):
         self._camera_pos = cfg.position.copy()
         self._lookat_pos = cfg.look_at.copy()
         self._up = cfg.up.copy()
+        self._moved = True
 
 
 class EarthViewer:
@@ -177,12 +186,15 @@ class EarthViewer:
         if config is not None:
             self.load_config(config)
         self._image = None
+        self._sliders = None
 
     def load_config(self, path_or_config):
         cfg = path_or_config if isinstance(path_or_config, Config) else load_config(path_or_config)
         self.config = cfg
         self.camera.load(cfg)
+        self.camera.update_camera(0.0)          # the renderer gets the camera right here
         cfg.apply(self.renderer)
+        self._sliders = None                    # 'o' re-reads the slider values from the file (:213-236)
         self.renderer.reset_framebuffer()
 
     def save_config(self, path):
@@ -198,6 +210,43 @@ class EarthViewer:
             self.renderer.accumulate(n)
             left -= n
         self._image = self.renderer.fetch_image()
+        return self._image
+
+    def frame(self, spp=1, **sliders):
+        """ONE iteration of the reference's window loop (earth_viewer.py:203-317), with the GUI sliders passed as keywords
+        (sun_angle, sun_path_rot, fov, aspect_scale, exposure, selected_crf, gamma):
+          1. a moved camera is pushed to the renderer and marks the framebuffer for reset          (:206-213)
+          2. accumulate() x spp, fetch_image() — with the parameters of the PREVIOUS iteration     (:241-243)
+          3. slider changes: sun angle / sun path rotation / fov / aspect scale mark the framebuffer for reset;
+             exposure, camera response and gamma do not (display-only)                            (:268-305)
+          4. the scalars are written to the renderer, then the reset happens                       (:308-317)
+        Returns the displayed image of step 2."""
+        r = self.renderer
+        should_reset = False
+        if self.camera.update_camera(0.0):
+            r.set_camera_pos(*self.camera.position)
+            r.set_look_at(*self.camera.look_at)
+            r.set_up(*self.camera._up)
+            should_reset = True
+        r.accumulate(int(spp))                  # == accumulate() x spp, bit for bit
+        self._image = r.fetch_image()
+        if self._sliders is None:               # current_* of earth_viewer.py:191-199, read once when the loop starts
+            self._sliders = {"sun_angle": r.sun_angle[None], "sun_path_rot": r.sun_path_rot[None], "fov": r.fov[None],
+                             "aspect_scale": r.aspect_scale[None], "exposure": r.exposure[None],
+                             "selected_crf": r.selected_crf[None], "gamma": r.gamma[None]}
+        cur = self._sliders
+        for k, v in sliders.items():
+            if k not in cur:
+                raise TypeError("unknown slider %r" % k)
+            if v != cur[k]:
+                if k in ("sun_angle", "sun_path_rot", "fov", "aspect_scale"):
+                    should_reset = True
+                cur[k] = v
+        r.sun_angle[None] = cur["sun_angle"]; r.sun_path_rot[None] = cur["sun_path_rot"]
+        r.fov[None] = cur["fov"]; r.aspect_scale[None] = cur["aspect_scale"]
+        r.exposure[None] = cur["exposure"]; r.gamma[None] = cur["gamma"]; r.selected_crf[None] = cur["selected_crf"]
+        if should_reset:
+            r.reset_framebuffer()
         return self._image
 
     def save(self, path):

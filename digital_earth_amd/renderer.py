@@ -59,7 +59,7 @@ class Renderer:
                       "synthetic": procedural maps generated on the GPU (the reference ships no maps, README.md:31-32);
                       "constant": 1x1 maps (BASELINE cfg1: flat albedo, no topography, no clouds)
       texture_quality 0/1/2 — lib/textures.py:1 (resolutions of the tier are used for synthetic maps too)
-      texture_size    override (w, h) for every synthetic map (tests)
+      texture_size    override (w, h) for every synthetic map, or {slot: (w, h)} per map (tests)
       cloud_heavy     synthetic cloud variant of BASELINE cfg4
       seed            base seed of the per-sample RNG streams
     """
@@ -102,6 +102,7 @@ class Renderer:
         self._texture_plan = self._plan_textures(texture_source, texture_dir, texture_quality, texture_size,
                                                  cloud_heavy, synth_seed)
         self._textures_copied = False
+        self._bound = None           # (tensor, stream) kept alive while the context points at them (parallel.DistributedFrame)
 
         # LUTs (renderer.py:96-134)
         self.crf_names = []
@@ -182,7 +183,7 @@ class Renderer:
         if source == "synthetic":
             plan = []
             for s in range(7):
-                w, h = size if size is not None else table[s][1]
+                w, h = (size[s] if isinstance(size, dict) else size) if size is not None else table[s][1]
                 plan.append(("synthetic", s, (int(w), int(h), int(synth_seed), 1 if cloud_heavy else 0)))
             return plan
         if source == "constant":
@@ -212,6 +213,15 @@ class Renderer:
         cie, s2s, o3, crf = self._luts
         check(self._lib.de_upload_luts(self._h, cie.ctypes.data, s2s.ctypes.data, o3.ctypes.data, crf.ctypes.data,
                                        crf.shape[1]))
+        self._textures_copied = True
+
+    def share_textures_from(self, other):
+        """Use `other`'s device-resident maps and LUTs (same GPU) instead of uploading / generating copies: a second
+        frame in flight costs no second 9 GB.  Keeps a reference to `other` so it outlives this renderer."""
+        if not other._textures_copied:
+            other.copy_textures()
+        check(self._lib.de_share_textures(self._h, other._h))
+        self._lender = other
         self._textures_copied = True
 
     def download_texture(self, slot):
@@ -373,6 +383,30 @@ class Renderer:
     def bind_hdr(self, device_ptr, n_floats):
         """Accumulate into caller-owned device memory (e.g. a torch tensor) instead of the library's buffer."""
         check(self._lib.de_bind_hdr(self._h, ctypes.c_void_p(device_ptr), int(n_floats)))
+
+    def unbind(self):
+        """Back to the library's own HDR buffer and stream (undoes bind_hdr / set_stream)."""
+        check(self._lib.de_bind_hdr(self._h, None, 0))
+        check(self._lib.de_set_stream(self._h, None))
+        self._bound = None
+
+    # in-library collective (include/digital_earth.h: de_comm_*, de_reduce)
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        check(self._lib.de_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        check(self._lib.de_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        check(self._lib.de_comm_destroy(self._h))
+
+    def reduce(self, root=0, comm=None):
+        """Sum the HDR buffers of all ranks onto `root` (RCCL, in place, on the context's stream)."""
+        check(self._lib.de_reduce(self._h, ctypes.c_void_p(comm) if comm else None, int(root)))
 
     def render_to_image_device(self):
         """Run the display transform and leave the (W, H, 3) image on the device; returns its address."""

@@ -99,6 +99,10 @@ int de_upload_texture(de_ctx* ctx, int slot, const uint8_t* texels, int width, i
 /* Synthetic stand-in for the NASA maps that the reference does not ship: generated on the GPU,
  * deterministic in (slot, width, height, seed, variant).  variant 1 = cloud-heavy (BASELINE cfg4). */
 int de_generate_texture(de_ctx* ctx, int slot, int width, int height, uint32_t seed, int variant);
+/* Let `dst` use the maps and LUTs that `src` holds on the same device instead of copies of its own (a second frame in
+ * flight, a second view of the same Earth: 9 GB at quality 2).  Read-only borrowing: `src` must outlive `dst` or `dst`
+ * must upload / generate maps of its own before `src` is destroyed; the borrowed maps keep `src`'s address mode. */
+int de_share_textures(de_ctx* dst, de_ctx* src);
 /* Read a map back as uploaded (row-major, `channels` bytes per texel) — lets tests hand the same texels to the oracle. */
 int de_download_texture(de_ctx* ctx, int slot, uint8_t* out, uint64_t out_bytes);
 int de_texture_info(de_ctx* ctx, int slot, int* width, int* height, int* channels);
@@ -142,7 +146,20 @@ int de_hdr_device_ptr(de_ctx* ctx, void** ptr, uint64_t* n_floats);
 /* Use caller-owned device memory (n_floats >= W*H*3, e.g. a torch tensor's data_ptr) as the HDR buffer; the current
  * contents are kept as the accumulation state.  ptr = NULL returns to the library's own buffer. */
 int de_bind_hdr(de_ctx* ctx, void* device_ptr, uint64_t n_floats);
+/* hip_stream = NULL: back to a stream owned by the context. */
 int de_set_stream(de_ctx* ctx, void* hip_stream);
+
+/* The collective of the tile partition inside the library (SURVEY §8b `de_reduce`, §8e): one in-place
+ * ncclReduce(sum, f32, count = W*H*3) of the HDR buffer to `root` over RCCL / xGMI, enqueued on the context's stream
+ * after the accumulate launches.  librccl.so is bound at run time (dlopen; an instance already in the process, e.g.
+ * PyTorch's, is reused), so single-GPU users never load it.
+ *   de_comm_unique_id   rank 0: ncclGetUniqueId into a 128-byte buffer; the HOST carries those bytes to the other ranks
+ *   de_comm_init        every rank: ncclCommInitRank (collective call); the communicator belongs to the context
+ *   de_reduce           comm = NULL uses the context's communicator; otherwise an ncclComm_t the host framework owns */
+int de_comm_unique_id(void* out128);
+int de_comm_init(de_ctx* ctx, const void* id128, int rank, int world);
+int de_comm_destroy(de_ctx* ctx);
+int de_reduce(de_ctx* ctx, void* comm, int root);
 int de_synchronize(de_ctx* ctx);
 
 /* Timing of the last de_accumulate on the context's own stream, measured with HIP events (ms). */

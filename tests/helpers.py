@@ -40,13 +40,11 @@ def copy_params(src):
 
 
 def load_preset(name):
-    """camera/sun preset from digital_earth_amd/data/configs (the reference's `config - *.txt` files)."""
-    import os
-    path = os.path.join(luts.CONFIG_DIR, name)
-    with open(path) as f:
-        lines = [l.strip() for l in f.readlines() if l.strip()]
-    pos = [float(x) for x in lines[0].split()]
-    look = [float(x) for x in lines[1].split()]
-    up = [float(x) for x in lines[2].split()]
-    return dict(pos=pos, look_at=look, up=up, fov=float(lines[3]), aspect_scale=float(lines[4]), exposure=float(lines[5]),
-                crf=int(lines[6]), gamma=float(lines[7]), sun_angle=float(lines[8]), sun_path_rot=float(lines[9]))
+    """camera/sun preset from digital_earth_amd/data/configs (the reference's `config - *.txt` files), read with the
+    PRODUCT's parser (digital_earth_amd.earth_viewer.load_config; checked against the file's tokens in
+    tests/test_host_logic.py and tests/test_gpu_round2.py)."""
+    from digital_earth_amd.earth_viewer import load_config
+    c = load_config(name)
+    return dict(pos=[float(x) for x in c.position], look_at=[float(x) for x in c.look_at], up=[float(x) for x in c.up], fov=c.fov,
+                aspect_scale=c.aspect_scale, exposure=c.exposure, crf=c.selected_crf, gamma=c.gamma, sun_angle=c.sun_angle,
+                sun_path_rot=c.sun_path_rot)

@@ -431,8 +431,11 @@ def test_edge_cases_of_accumulate(Renderer):
     r = Renderer((256, 256), (0, 1, 0), texture_source="constant")
     r.accumulate(0)                                   # nothing to do: state unchanged
     assert r.current_spp == 0 and (r.fetch_hdr() == 0).all()
-    with pytest.raises(DigitalEarthError):            # 65536 pixels x 70000 spp >= 2^32 work items: must be split by the caller
-        r.accumulate(70000)
+    with pytest.raises(DigitalEarthError):
+        r._lib.de_accumulate  # noqa: B018  (large requests are split inside de_accumulate: tests/test_gpu_round2.py)
+        check_rc = r._lib.de_accumulate(r._h, -1, 0, 0, 1)
+        from digital_earth_amd._native import check
+        check(check_rc)
     with pytest.raises(ValueError):
         r.set_tile_partition(3, 2)
     r.set_tile_partition(1, 2)

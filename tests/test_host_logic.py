@@ -22,6 +22,7 @@ def test_camera_defaults_and_motion():
     p0 = c.position.copy()
     c.move(c.target_dir, 0.1)
     assert np.linalg.norm(c.position - p0) > 0
+    assert c.update_camera(0.1) is True       # earth_viewer.py:146-155: reports the change once
     assert c.update_camera(0.1) is False
 
 
@@ -34,6 +35,20 @@ def test_config_round_trip(tmp_path):
         assert getattr(a, k) == getattr(b, k)
     assert (a.position == b.position).all() and (a.look_at == b.look_at).all() and (a.up == b.up).all()
     assert len(open(p).read().splitlines()) == 10
+
+
+def test_presets_parse_to_the_files_tokens():
+    """The product's 10-line preset parser against the raw tokens of the reference's three preset files."""
+    import os
+    from digital_earth_amd import luts
+    for name in ("config - florida.txt", "config - sunset hurricane.txt", "config - Apollo 11.txt"):
+        with open(os.path.join(luts.CONFIG_DIR, name)) as f:
+            want = [float(t) for t in f.read().split()]
+        assert len(want) == 16
+        c = load_config(name)
+        got = list(c.position) + list(c.look_at) + list(c.up) + [c.fov, c.aspect_scale, c.exposure, c.selected_crf, c.gamma,
+                                                                  c.sun_angle, c.sun_path_rot]
+        assert got == want, name
 
 
 def test_tile_partition_masks():
