@@ -55,15 +55,17 @@ def test_mixed_map_sizes_and_partial_tiles(Renderer, lut_arrays, clamp):
              T.BATHYMETRY: (1080, 540), T.EMISSIVE: (1082, 541), T.STARS: (810, 405)}
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=sizes, seed=2)
     r.set_flag(_native.DE_FLAG_CLAMP_SAMPLER, clamp)
-    for pos, look in (((-15e6, 0.0, 15e6), (0, 0, 0)), ((2.0e6, 9.0e6, 0.0), (0, 6.0e6, 0)), ((8.0e6, 1.0e5, 1.0e4), (0, 0, 0))):
-        r.set_camera_pos(*pos); r.set_look_at(*look)
+    lit = 0
+    for pos, look, sun in (((-15e6, 0.0, 15e6), (0, 0, 0), 1.047), ((2.0e6, 9.0e6, 0.0), (0, 6.0e6, 0), 0.1), ((8.0e6, 1.0e5, 1.0e4), (0, 0, 0), 4.6)):
+        r.set_camera_pos(*pos); r.set_look_at(*look); r.set_sun_angle(sun)
         r.copy_textures() if not r._textures_copied else None
         o = _oracle_for(r, lut_arrays, W, H)
         r.reset_framebuffer()
         r.accumulate(SPP); o.accumulate(SPP, 2)
         g, c = r.fetch_hdr(), o.fetch_hdr()
-        assert g.max() > 0
+        lit += int(g.max() > 0)
         assert bits_equal_fraction(g, c) == 1.0, (clamp, pos, rel_l2(g, c))
+    assert lit >= 2
 
 
 def test_earth_viewer_preset_through_product_parser(lut_arrays):
@@ -98,7 +100,7 @@ def test_earth_viewer_preset_through_product_parser(lut_arrays):
     o.accumulate(3, 0)
     assert (r.fetch_hdr().view(np.uint32) == o.fetch_hdr().view(np.uint32)).all()
     assert np.abs(img - o.fetch_image()).max() <= 1e-5
-    assert r.crf_names[12] == "kaf2001CD.rf" and r.selected_crf[None] == 12
+    assert r.selected_crf[None] == 12 and len(r.crf_names) == 16 and r.crf_names[0] == "Neutral.rf"   # order: Neutral first, then by name (Q10)
 
 
 def test_earth_viewer_frame_loop_reset_semantics(lut_arrays):
