@@ -38,7 +38,6 @@ DE_FLAG_FIXED_WAVELENGTH = 1 << 0
 DE_FLAG_CLAMP_SAMPLER = 1 << 1
 DE_FLAG_RAY_MARCHER = 1 << 2
 DE_FLAG_AGX = 1 << 3
-DE_FLAG_NO_FAST_DIVISION = 1 << 4
 
 # name -> (restype, argtypes): every symbol include/digital_earth.h declares
 _P = ctypes.c_void_p

@@ -1,4 +1,5 @@
 // aux_kernels.hip — everything around the hot kernel:
+//   dens_table_kernel   altitude table of the gas density profiles
 //   setup_kernel        per-frame constants + the 512-node wavelength table (lib/colour.py:13-48, pathtracer.py:332-343)
 //   display_kernel      Renderer._render_to_image + camera_response + openDR_transform (renderer.py:333-365,
 //                       lib/OpenDRT.py:325-473) + srgb_transfer (lib/colour.py:74-79)
@@ -99,35 +100,16 @@ __global__ void setup_kernel(SetupArgs s) {
         L.s2s_valid = 1.0f;
     }
     L.inv_max_ext_rmo = 1.0f / L.max_ext_rmo;
-    L.fast_div = 0.0f;       // enabled by verify_div_kernel
-    L.pad0 = 0.0f; L.pad1 = 0.0f;
+    L.pad0 = 0.0f; L.pad1 = 0.0f; L.pad2 = 0.0f;
     s.nodes[n] = L;
 }
 
-// Exhaustive proof obligation of de_div_rc for the per-wavelength majorants: for node blockIdx.y and every one of the
-// 2^23 significands of x (at two exponents), the 3-operation quotient must equal the IEEE quotient.  512 x 2^24 checks,
-// a few milliseconds, run when the LUTs or parameters change.  Nodes that pass get fast_div = 1.
-__global__ void __launch_bounds__(256) verify_div_kernel(LambdaNode* nodes, unsigned int* fail_counts) {
-    const int n = (int)blockIdx.y;
-    const float c = nodes[n].max_ext_rmo;
-    const float rc = nodes[n].inv_max_ext_rmo;
-    unsigned bad = 0;
-    for (unsigned m = blockIdx.x * blockDim.x + threadIdx.x; m < (1u << 24); m += gridDim.x * blockDim.x) {
-        const unsigned expo = (m >> 23) ? 140u : 127u;
-        const float x = de_u2f((expo << 23) | (m & 0x7fffffu));
-        const float q0 = x * rc;
-        const float r = de_fma(-q0, c, x);
-        const float q = de_fma(r, rc, q0);
-        bad += (de_f2u(q) != de_f2u(x / c)) ? 1u : 0u;
-    }
-    if (bad) atomicAdd(&fail_counts[n], bad);
-}
-__global__ void enable_fast_div_kernel(LambdaNode* nodes, const unsigned int* fail_counts) {
-    const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (n >= DE_N_NODES) return;
-    const float c = nodes[n].max_ext_rmo;
-    const bool usable = (c > 0x1p-60f && c < 0x1p+60f);     // keeps x * rc and the residual far from under/overflow
-    nodes[n].fast_div = (usable && fail_counts[n] == 0u) ? 1.0f : 0.0f;
+// get_density for every altitude a tracking step can see (DE_DENS_TABLE_N): the table IS the function, not an approximation.
+__global__ void __launch_bounds__(256) dens_table_kernel(float* table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DE_DENS_TABLE_N) return;
+    const vec3 d = get_density((float)i * 0.5f);
+    table[i * 3u] = d.x; table[i * 3u + 1u] = d.y; table[i * 3u + 2u] = d.z;
 }
 
 // ------------------------------------------------------------------------------------------------ display
@@ -401,6 +383,7 @@ __global__ void math_kernel(int fn, const float* a, const float* b, float* out, 
         case 12: r = de_log_unit(x); break;
         case 13: r = de_rcp_nr(x); break;
         case 14: r = de_exp_nonpos(x); break;
+        case 15: r = de_sqrt_nr(x); break;
         default: r = 0.0f;
     }
     out[k] = r;

@@ -143,8 +143,8 @@ struct de_ctx {
     int W = 0, H = 0;
     de_params p;
     bool params_dirty = true;     // FrameConsts must be rebuilt (any scalar parameter, the topography width)
-    bool nodes_dirty = true;      // the wavelength table and its division proof must be rebuilt (LUTs, address mode, fixed wavelength)
-    int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 10, tune_chunk = 128, tune_wpc = 16, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
+    bool nodes_dirty = true;      // the wavelength table must be rebuilt (LUTs, address mode, fixed wavelength)
+    int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 10, tune_chunk = 128, tune_wpc = 20, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -169,7 +169,7 @@ struct de_ctx {
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;
     uint32_t* d_work_counter = nullptr;
-    unsigned int* d_div_fail = nullptr;
+    float* d_dens_table = nullptr;   // get_density by altitude index (DE_DENS_TABLE_N x 3)
     uint2* d_contrib = nullptr;  // v2 per-sample contributions
     size_t contrib_items = 0;
     int n_cus = 256;
@@ -229,21 +229,10 @@ int run_setup(de_ctx* c) {
     s.srgb2spec = c->d_srgb2spec; s.o3 = c->d_o3;
     s.fc = c->d_fc; s.nodes = c->d_nodes; s.node_val = c->d_node_val;
     s.do_nodes = c->nodes_dirty ? 1 : 0;
-    // camera / sun / display changes rebuild the frame constants only (one wave); the 512-node wavelength table and the
-    // exhaustive division proof depend on the LUTs, the address mode and the fixed wavelength alone
+    // camera / sun / display changes rebuild the frame constants only (one wave); the 512-node wavelength table depends on
+    // the LUTs, the address mode and the fixed wavelength alone
     hipLaunchKernelGGL(setup_kernel, dim3(c->nodes_dirty ? DE_N_NODES / 64 : 1), dim3(64), 0, c->stream, s);
     HIP_TRY(hipGetLastError());
-    if (c->nodes_dirty) {
-        // prove (exhaustively, on the device) for which wavelength nodes the 3-operation division by the majorant is exact
-        if (c->p.flags & DE_FLAG_NO_FAST_DIVISION) {      // test hook: every node "fails" the proof
-            HIP_TRY(hipMemsetAsync(c->d_div_fail, 0xFF, DE_N_NODES * sizeof(unsigned int), c->stream));
-        } else {
-            HIP_TRY(hipMemsetAsync(c->d_div_fail, 0, DE_N_NODES * sizeof(unsigned int), c->stream));
-            hipLaunchKernelGGL(verify_div_kernel, dim3(64, DE_N_NODES), dim3(256), 0, c->stream, c->d_nodes, c->d_div_fail);
-        }
-        hipLaunchKernelGGL(enable_fast_div_kernel, dim3(DE_N_NODES / 64), dim3(64), 0, c->stream, c->d_nodes, (const unsigned int*)c->d_div_fail);
-        HIP_TRY(hipGetLastError());
-    }
     c->params_dirty = false; c->nodes_dirty = false;
     return DE_OK;
 }
@@ -281,7 +270,7 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
         TexRGB o; o.data = t.packed; o.w = t.w; o.h = t.h; o.wf = (float)t.w; o.hf = (float)t.h;
         return o;
     };
-    a->fc = c->d_fc; a->nodes = c->d_nodes; a->node_val = c->d_node_val;
+    a->fc = c->d_fc; a->nodes = c->d_nodes; a->node_val = c->d_node_val; a->dens_table = c->d_dens_table;
     a->topo = r8(DE_TEX_TOPOGRAPHY); a->ocean = r8(DE_TEX_OCEAN); a->clouds = r8(DE_TEX_CLOUDS);
     a->bathy = r8(DE_TEX_BATHYMETRY); a->emissive = r8(DE_TEX_EMISSIVE);
     a->albedo = rgb(DE_TEX_ALBEDO); a->stars = rgb(DE_TEX_STARS);
@@ -302,7 +291,7 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
         hipError_t me = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
         if (me != hipSuccess) return me;
-        // waves: one per owned tile at most (a tile's first 64 work items), and no more than the CUs hold at 4 waves/SIMD
+        // waves: one per owned tile at most (a tile's first 64 work items), and no more than the CUs hold at 5 waves/SIMD (c->tune_wpc = 20 per CU)
         // (more would only queue behind the resident ones and find the work counter exhausted; they would also keep the
         // small kernels of the other frame in flight — accumulate, display, memsets — waiting for a slot)
         const unsigned waves_per_block = DE_V2_BLOCK / 64;
@@ -315,10 +304,11 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
         if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
         return hipGetLastError();
     }
-    if (!clamp && !march) hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
-    else if (clamp && !march) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
-    else if (!clamp && march) hipLaunchKernelGGL((render_kernel<false, true, MODE>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((render_kernel<true, true, MODE>), grid, block, 0, c->stream, a);
+    if (march) {
+        if (clamp) hipLaunchKernelGGL((ray_march_kernel<true, MODE>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((ray_march_kernel<false, MODE>), grid, block, 0, c->stream, a);
+    } else if (clamp) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
     return hipGetLastError();
 }
 
@@ -424,13 +414,17 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, DE_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_div_fail, DE_N_NODES * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(&c->d_dens_table, (size_t)DE_DENS_TABLE_N * 3 * sizeof(float));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_o3, 441 * sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_hdr, 0, npx * 3 * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dens_table_kernel, dim3(DE_DENS_TABLE_N / 256), dim3(256), 0, c->stream, c->d_dens_table);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         std::string msg = std::string("de_create: ") + hipGetErrorString(e);
         de_destroy(c);
@@ -447,7 +441,7 @@ int de_destroy(de_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_div_fail};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_dens_table};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -814,7 +808,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
 }
 
 int de_debug_math(de_ctx* c, int fn, const float* a, const float* b, float* out, uint64_t n) {
-    if (!c || !a || !out || fn < 0 || fn > 14) return fail(DE_ERR_INVALID, "bad arguments");
+    if (!c || !a || !out || fn < 0 || fn > 31) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     struct Bufs {   // freed on every exit path
         float *da = nullptr, *db = nullptr, *dout = nullptr;

@@ -22,7 +22,8 @@ DE_DEV float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DE_DEV float length(vec3 a) { return de_sqrt(dot(a, a)); }
 // |a| for positions (|a|^2 ~ 4e13) and other vectors known to be far from the under/overflow ranges
 DE_DEV float length_nr(vec3 a) { return de_sqrt_nr(dot(a, a)); }
-DE_DEV vec3 normalized(vec3 a) { return a / length(a); }
+// Vector.normalized() under contract 2: v * RN(1 / |v|) — one reciprocal shared by the three components
+DE_DEV vec3 normalized(vec3 a) { return a * (1.0f / length(a)); }
 DE_DEV vec3 cross(vec3 a, vec3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DE_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 DE_DEV vec3 mix3(vec3 a, vec3 b, float t) { return v3(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
@@ -84,7 +85,6 @@ struct TexF3 {
     int w, h;
 };
 
-DE_DEV float unorm8(uint32_t b) { return DE_DIVC_NG((float)b, 255.0f); }   // == (float)b / 255.0f, b in 0..255
 
 struct TapCount { uint32_t r8, rgb; };
 
@@ -108,10 +108,11 @@ DE_DEV uint32_t tap_r8_issue(const TexR8& t, float u, float v, float* fx_out, fl
     return t.data[idx];
 }
 DE_DEV float tap_r8_finish(uint32_t q, float fx, float fy) {
-    float t00 = unorm8(q & 255u), t10 = unorm8((q >> 8) & 255u), t01 = unorm8((q >> 16) & 255u), t11 = unorm8(q >> 24);
+    // contract 2: the bilinear filter runs on the byte values (exact small integers), the result is scaled by RN(1/255)
+    float t00 = (float)(q & 255u), t10 = (float)((q >> 8) & 255u), t01 = (float)((q >> 16) & 255u), t11 = (float)(q >> 24);
     float a = de_fma(t10 - t00, fx, t00);
     float b = de_fma(t11 - t01, fx, t01);
-    return de_fma(b - a, fy, a);
+    return de_fma(b - a, fy, a) * DE_INV_255;
 }
 template <bool CLAMP>
 DE_DEV float tap_r8(const TexR8& t, float u, float v) {
@@ -138,11 +139,11 @@ DE_DEV vec3 tap_rgb(const TexRGB& t, float u, float v) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         int sh = ch * 8;
-        float t00 = unorm8((q00 >> sh) & 255u), t10 = unorm8((q10 >> sh) & 255u);
-        float t01 = unorm8((q01 >> sh) & 255u), t11 = unorm8((q11 >> sh) & 255u);
+        float t00 = (float)((q00 >> sh) & 255u), t10 = (float)((q10 >> sh) & 255u);
+        float t01 = (float)((q01 >> sh) & 255u), t11 = (float)((q11 >> sh) & 255u);
         float a = de_fma(t10 - t00, fx, t00);
         float b = de_fma(t11 - t01, fx, t01);
-        o[ch] = de_fma(b - a, fy, a);
+        o[ch] = de_fma(b - a, fy, a) * DE_INV_255;
     }
     return v3(o[0], o[1], o[2]);
 }
@@ -181,9 +182,9 @@ DE_DEV vec2_ rsi(vec3 pos, vec3 dir, float r) {
 }
 DE_DEV vec2_ sphere_UV_map(vec3 n) {                                                                   // :25-28
     vec2_ o;
-    // unguarded: |angle| <= pi; an angle below 2^-100 gives a quotient that the "+ 1" / "+ 0.5" absorbs whatever its last bits
-    o.x = (DE_DIVC_NG(de_atan2(n.z, -n.x), (float)M_PI) + 1.0f) / 2.0f;
-    o.y = DE_DIVC_NG(de_asin(n.y), (float)M_PI) + 0.5f;
+    // contract 2: (atan2 / pi + 1) / 2 and asin / pi + 0.5 as one fused multiply-add each with RN(1/2pi), RN(1/pi)
+    o.x = de_fma(de_atan2(n.z, -n.x), DE_INV_2PI, 0.5f);
+    o.y = de_fma(de_asin(n.y), DE_INV_PI, 0.5f);
     return o;
 }
 DE_DEV float fract_(float x) { return x - de_floor(x); }

@@ -43,16 +43,19 @@ struct LambdaNode {
     float max_ext_rmo;       //                                  pathtracer.py:355
     float c0, c1, c2;        // srgb_to_spectrum coefficients mix(lut[w], lut[w+1], f)   lib/colour.py:64-70
     float s2s_valid;         // 1 if 0 < w < 299 else 0
-    float inv_max_ext_rmo;   // RN(1 / max_ext_rmo)
-    float fast_div;          // 1 if x / max_ext_rmo == de_div_rc(x, max_ext_rmo, inv) for every significand of x (checked on the device)
-    float pad0, pad1;
+    float inv_max_ext_rmo;   // RN(1 / max_ext_rmo): tracking divides by the majorant as a product with this (contract 2)
+    float pad0, pad1, pad2;
 };
 #define DE_N_NODES 512
+// Altitude table of get_density: entry i = (Rayleigh, Mie, ozone) density at h = i / 2 metres, for every f32-representable
+// altitude of a point with |pos| in [2^22, 2^23) below 131 072 m (3 MB).
+#define DE_DENS_TABLE_N 262144
 
 struct RenderArgs {
     const FrameConsts* fc;
     const LambdaNode* nodes;
     const float* node_val;        // [256] CDF value tested at inner node n (lib/colour.py:28)
+    const float* dens_table;      // [DE_DENS_TABLE_N][3]
     TexR8 topo, ocean, clouds, bathy, emissive;
     TexRGB albedo, stars;
     float* hdr;                   // [H][W][3]

@@ -67,17 +67,18 @@ DE_DEV float de_div_y(float a_, float b, float y) {
     return de_fma(r, y, q);
 }
 
-// sqrt for x = 0 or a normal x in [2^-60, 2^60]: v_sqrt_f32 (<= 1 ulp) corrected to the nearest value with two residual
-// tests — the core of the compiler's IEEE expansion without its denormal scaling and class checks (21 -> 9 operations).
-// tests/test_gpu_parity.py::test_fast_sqrt_is_correctly_rounded compares it with the IEEE result for every significand
-// at both exponent parities.
+// sqrt for x = 0 or a normal x in [2^-63, 2^64]: v_rsq_f32 (<= 1 ulp), s = x * y, and one coupled Newton step whose residual
+// x - s*s is exact in an fma.  On gfx950 that IS the correctly rounded root for every significand at every exponent of
+// that range (tools/exhaustive_math.py sqrt_rsq: 128 exponents x 2^23 significands, 0 mismatches; also
+// tests/test_gpu_parity.py::test_fast_sqrt_is_correctly_rounded) — 7 operations instead of the 21 of the compiler's
+// IEEE expansion.  NaN and negative arguments give NaN; zero is selected explicitly (0 * rsq(0) would be NaN).
 DE_DEV float de_sqrt_nr(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float s_dn = de_u2f(de_f2u(s) - 1u), s_up = de_u2f(de_f2u(s) + 1u);
-    float d_dn = de_fma(-s_dn, s, x), d_up = de_fma(-s_up, s, x);
-    s = (d_dn <= 0.0f) ? s_dn : s;
-    s = (d_up > 0.0f) ? s_up : s;
-    return s;
+    float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    float h = 0.5f * y;
+    float e = de_fma(-s, s, x);
+    float r = de_fma(e, h, s);
+    return (x == 0.0f) ? 0.0f : r;
 }
 
 // 1 / b for a normal b in [2^-60, 2^60]: v_rcp_f32 (<= 1 ulp) and one Newton step with the residual exact in an fma.
@@ -169,34 +170,6 @@ DE_DEV float de_log(float x) {
     return (x != x || x < 0.0f) ? __builtin_nanf("") : res;
 }
 
-// de_log for an argument that is 0 or a normal number in (0, 1) — rng_next's k * 2^-24: the same operations as de_log
-// without the selects that cannot fire on that domain (subnormal scaling, +inf, NaN / negative).  Bit-identical to
-// de_log on all 2^24 such arguments (tests/test_gpu_parity.py::test_log_of_a_random_draw).
-DE_DEV float de_log_unit(float x) {
-    const uint32_t ix = de_f2u(x);
-    int e = (int)(ix >> 23) - 127;
-    float f = de_u2f((ix & 0x007fffffu) | 0x3f800000u);
-    if (f > 0x1.6a09e6p+0f) { f = f * 0.5f; e += 1; }
-    f = f - 1.0f;
-    float p = 0x1.16d79ep-4f;
-    p = de_fma(p, f, -0x1.dfb3a4p-4f);
-    p = de_fma(p, f, 0x1.e69804p-4f);
-    p = de_fma(p, f, -0x1.fbdbap-4f);
-    p = de_fma(p, f, 0x1.2338e2p-3f);
-    p = de_fma(p, f, -0x1.555e68p-3f);
-    p = de_fma(p, f, 0x1.99a4b4p-3f);
-    p = de_fma(p, f, -0x1.000002p-2f);
-    p = de_fma(p, f, 0x1.555548p-2f);
-    const float f2 = f * f;
-    const float fe = (float)e;
-    float y = (f * f2) * p;
-    y = de_fma(fe, DE_LN2_LO, y);
-    y = de_fma(-0.5f, f2, y);
-    const float z = f + y;
-    const float res = de_fma(fe, DE_LN2_HI, z);
-    return (x == 0.0f) ? -DE_INF : res;
-}
-
 DE_DEV void de_sincos(float x, float* s_out, float* c_out) {
     float k = de_floor(de_fma(x, DE_2OPI, 0.5f));
     float r = de_fma(-k, DE_PIO2_HI, x);
@@ -224,47 +197,73 @@ DE_DEV void de_sincos(float x, float* s_out, float* c_out) {
 DE_DEV float de_sin(float x) { float s, c; de_sincos(x, &s, &c); return s; }
 DE_DEV float de_cos(float x) { float s, c; de_sincos(x, &s, &c); return c; }
 
-// atan2(y, x) in (-pi, pi]; atan2(0, 0) := 0
+// ------------------------------------------------------------------------------------------------ contract 2 (round 2)
+// The functions of the hot loops, re-stated for the accuracy the path needs (tools/fit_f32_polys.py fit_c2)
+// instead of 2 ulp, and with every quotient by a shared or constant divisor written as a product with its correctly
+// rounded reciprocal.  Same rule as before: a fixed sequence of correctly rounded binary32 operations, stated
+// independently in oracle/oracle_math.h and compared bit for bit.
+#define DE_INV_PI ((float)(1.0 / 3.14159265358979323846))
+#define DE_INV_2PI ((float)(0.5 / 3.14159265358979323846))
+#define DE_INV_255 ((float)(1.0 / 255.0))
+#define DE_LN2 0x1.62e430p-1f
+
+// atan2(y, x) for |x|, |y| <= 2^60: q = min * RN(1 / max), 6-coefficient odd polynomial (3.5e-7 rad).  Both arguments
+// below 2^-60 (or zero) give 0.
 DE_DEV float de_atan2(float y, float x) {
     float ax = de_abs(x), ay = de_abs(y);
     bool swap = ay > ax;
     float mx = swap ? ay : ax;
     float mn = swap ? ax : ay;
-    float a = mn / mx;
+    float a = mn * de_rcp_nr(mx);
     float s = a * a;
-    float p = -0x1.d668cp-10f;
-    p = de_fma(p, s, 0x1.65b58ap-7f);
-    p = de_fma(p, s, -0x1.feccc6p-6f);
-    p = de_fma(p, s, 0x1.dabbfap-5f);
-    p = de_fma(p, s, -0x1.582c3cp-4f);
-    p = de_fma(p, s, 0x1.c09542p-4f);
-    p = de_fma(p, s, -0x1.242104p-3f);
-    p = de_fma(p, s, 0x1.9991e4p-3f);
-    p = de_fma(p, s, -0x1.55553ep-2f);
+    float p = 0x1.e50bcap-8f;
+    p = de_fma(p, s, -0x1.23a7dep-5f);
+    p = de_fma(p, s, 0x1.50f1cep-4f);
+    p = de_fma(p, s, -0x1.12821cp-3f);
+    p = de_fma(p, s, 0x1.96cb56p-3f);
+    p = de_fma(p, s, -0x1.5540c2p-2f);
     float r = de_fma(a * s, p, a);
     if (swap) r = DE_PIO2 - r;
     if (x < 0.0f) r = DE_PI - r;
     if (y < 0.0f) r = -r;
-    return (mx == 0.0f) ? 0.0f : r;
+    return (mx < 0x1p-60f) ? 0.0f : r;
 }
 
-// asin, argument clamped to [-1, 1]
+// asin, argument clamped to [-1, 1]: 4-coefficient polynomial (6e-8 rad)
 DE_DEV float de_asin(float x) {
     float ax = de_abs(x);
     if (ax > 1.0f) ax = 1.0f;
     bool big = ax > 0.5f;
     float s = big ? (1.0f - ax) * 0.5f : ax * ax;
-    float t = big ? de_sqrt_nr(s) : ax;           // s is 0 or in [2^-25, 1/4]: the short correctly-rounded sqrt applies
-    float p = 0x1.3513acp-5f;
-    p = de_fma(p, s, 0x1.d3dfe8p-7f);
-    p = de_fma(p, s, 0x1.04f064p-5f);
-    p = de_fma(p, s, 0x1.6ca29p-5f);
-    p = de_fma(p, s, 0x1.3338d6p-4f);
-    p = de_fma(p, s, 0x1.55554cp-3f);
+    float t = big ? de_sqrt_nr(s) : ax;           // s is 0 or in [2^-25, 1/4]
+    float p = 0x1.a7813ap-5f;
+    p = de_fma(p, s, 0x1.409a72p-5f);
+    p = de_fma(p, s, 0x1.35737ap-4f);
+    p = de_fma(p, s, 0x1.554bf8p-3f);
     float r = de_fma(t * s, p, t);
     if (big) r = de_fma(-2.0f, r, DE_PIO2);
     r = (x < 0.0f) ? -r : r;
     return (x != x) ? x : r;
+}
+
+// log of a random draw x = k * 2^-24, k in [0, 2^24): mantissa reduced to [sqrt(1/2), sqrt(2)) by integer arithmetic on
+// the bits, 6-coefficient polynomial (2.8e-7 relative), one ln 2 constant.  log(0) = -inf.
+DE_DEV float de_log_unit(float x) {
+    const uint32_t t = de_f2u(x) + 0x004afb0du;                    // + (bits(1) - bits(sqrt(1/2)))
+    const int e = (int)(t >> 23) - 127;
+    const float f = de_u2f((t & 0x007fffffu) + 0x3f3504f3u) - 1.0f;
+    float p = -0x1.a34a8ap-4f;
+    p = de_fma(p, f, 0x1.4875bep-3f);
+    p = de_fma(p, f, -0x1.5ed6f8p-3f);
+    p = de_fma(p, f, 0x1.980734p-3f);
+    p = de_fma(p, f, -0x1.ffa98cp-3f);
+    p = de_fma(p, f, 0x1.5557bep-2f);
+    const float f2 = f * f;
+    float y = (f * f2) * p;
+    y = de_fma(-0.5f, f2, y);
+    const float z = f + y;
+    const float res = de_fma((float)e, DE_LN2, z);
+    return (x == 0.0f) ? -DE_INF : res;
 }
 
 DE_DEV float de_pow(float a, float b) {

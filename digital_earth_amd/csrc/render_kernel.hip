@@ -20,7 +20,9 @@ enum { NULL_EVENT = 0, ABSORB_EVENT = 1, SCATTER_EVENT = 2 };
 
 struct Work { uint32_t taps_r8, taps_rgb, sphere_steps, tracking_steps, vertices; };
 
-template <bool CLAMP>
+// TABLE: gas densities from the altitude table (de_kernels.h DE_DENS_TABLE_N) instead of four exponentials per point —
+// the ray marcher evaluates 64 x 17 points per bounce.  Same values by construction (the table holds get_density itself).
+template <bool CLAMP, bool TABLE = false>
 struct Tracer {
     const RenderArgs& a;
     const FrameConsts& fc;
@@ -30,7 +32,7 @@ struct Tracer {
     // pathtracer.py:11-14
     DE_DEV float land_sdf(vec3 pos) {
         float len = length(pos);
-        vec3 n = pos / len;
+        vec3 n = pos * (1.0f / len);            // normalized() under contract 2
         wk.taps_r8++;
         return len - DE_PLANET_R - fc.land_height_scale * sphere_tap_r8<CLAMP>(a.topo, n);
     }
@@ -61,9 +63,9 @@ struct Tracer {
         float r = length(pos);
         float density = 0.0f;
         if (r > DE_CLOUDS_LOWER && r < DE_CLOUDS_UPPER) {
-            float h = (r - DE_CLOUDS_LOWER) / DE_CLOUDS_THICKNESS;
+            float h = (r - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
             wk.taps_r8++;
-            float cloud_texture = sphere_tap_r8<CLAMP>(a.clouds, pos / r);
+            float cloud_texture = sphere_tap_r8<CLAMP>(a.clouds, pos * (1.0f / r));
             float column_height = cloud_texture;
             const float split = 0.2f;
             density = (h - split < column_height * (float)(1.0 - 0.2) && split - h < column_height * split) ? de_max(cloud_texture, 0.4f) : 0.0f;
@@ -71,17 +73,28 @@ struct Tracer {
         return density * DE_CLOUDS_DENSITY;
     }
     DE_DEV vec3 gas_density(vec3 pos) {   // volume.get_density(volume.get_elevation(pos))
+        if (TABLE) {
+            // |pos| in [2^22, 2^23) m has a spacing of 0.5 m: h is an exact multiple of 0.5 and 2h is the table index
+            const float len = de_sqrt_nr((pos.x * pos.x + pos.y * pos.y) + pos.z * pos.z);
+            const float h2 = de_max(len - DE_PLANET_R, 0.0f) * 2.0f;
+            if (h2 < (float)DE_DENS_TABLE_N) {
+                const float* dt = a.dens_table + (size_t)(uint32_t)(int)h2 * 3u;
+                return v3(dt[0], dt[1], dt[2]);
+            }
+            return get_density(len - DE_PLANET_R);
+        }
         return get_density(de_sqrt((pos.x * pos.x + pos.y * pos.y) + pos.z * pos.z) - DE_PLANET_R);
     }
     // pathtracer.py:77-115 with extinctions = (r, m, o, 0)
     DE_DEV void delta_tracking_rmo(Rng& rng, vec3 ray_pos, vec3 ray_dir, float t_start, float t_max, vec3 ext, float max_ext,
                                    int* event_out, float* t_out, int* id_out) {
         float t = t_start;
+        const float inv_max = 1.0f / max_ext;      // contract 2: quotients by the majorant are products with RN(1 / majorant)
         ray_pos = ray_pos + t * ray_dir;
         int id = 0;
         int event = NULL_EVENT;
         while (t < t_max) {
-            float t_step = -de_log(rng_next(rng)) / max_ext;
+            float t_step = -de_log_unit(rng_next(rng)) * inv_max;
             ray_pos = ray_pos + t_step * ray_dir;
             t += t_step;
             wk.tracking_steps++;
@@ -89,15 +102,15 @@ struct Tracer {
             vec3 es = ext * gas_density(ray_pos);
             float rand = rng_next(rng);
             float sum = (es.x + es.y) + es.z;
-            if (rand < sum / max_ext) {
+            if (rand < sum * inv_max) {
                 float cmf = es.x;
-                if (!(rand < cmf / max_ext)) {
+                if (!(rand < cmf * inv_max)) {
                     id = 1;
                     cmf += es.y;
-                    if (!(rand < cmf / max_ext)) {
+                    if (!(rand < cmf * inv_max)) {
                         id = 2;
                         cmf += es.z;
-                        if (!(rand < cmf / max_ext)) id = 3;
+                        if (!(rand < cmf * inv_max)) id = 3;
                     }
                 }
                 const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));   // pathtracer.py:263-270
@@ -111,17 +124,18 @@ struct Tracer {
     DE_DEV void delta_tracking_cloud(Rng& rng, vec3 ray_pos, vec3 ray_dir, float t_start, float t_max, float ext_w, float max_ext,
                                      int* event_out, float* t_out) {
         float t = t_start;
+        const float inv_max = 1.0f / max_ext;      // contract 2: quotients by the majorant are products with RN(1 / majorant)
         ray_pos = ray_pos + t * ray_dir;
         int event = NULL_EVENT;
         while (t < t_max) {
-            float t_step = -de_log(rng_next(rng)) / max_ext;
+            float t_step = -de_log_unit(rng_next(rng)) * inv_max;
             ray_pos = ray_pos + t_step * ray_dir;
             t += t_step;
             wk.tracking_steps++;
             if (t >= t_max) break;
             float es = ext_w * get_clouds_density(ray_pos);
             float rand = rng_next(rng);
-            if (rand < es / max_ext) {
+            if (rand < es * inv_max) {
                 event = (rng_next(rng) < 0.99f) ? SCATTER_EVENT : ABSORB_EVENT;
                 break;
             }
@@ -131,16 +145,17 @@ struct Tracer {
     // pathtracer.py:117-143, gas part
     DE_DEV float ratio_tracking_rmo(Rng& rng, vec3 ray_pos, vec3 ray_dir, float t_start, float t_max, vec3 ext, float max_ext) {
         float t = t_start;
+        const float inv_max = 1.0f / max_ext;      // contract 2: quotients by the majorant are products with RN(1 / majorant)
         ray_pos = ray_pos + t * ray_dir;
         float tr = 1.0f;
         while (t < t_max) {
-            float t_step = -de_log(rng_next(rng)) / max_ext;
+            float t_step = -de_log_unit(rng_next(rng)) * inv_max;
             ray_pos = ray_pos + t_step * ray_dir;
             t += t_step;
             wk.tracking_steps++;
             if (t >= t_max) break;
             vec3 es = ext * gas_density(ray_pos);
-            tr *= 1.0f - ((es.x + es.y) + es.z) / max_ext;
+            tr *= 1.0f - ((es.x + es.y) + es.z) * inv_max;
             if (tr < 1e-5f) break;
         }
         return tr;
@@ -148,16 +163,17 @@ struct Tracer {
     // pathtracer.py:117-143, cloud part
     DE_DEV float ratio_tracking_cloud(Rng& rng, vec3 ray_pos, vec3 ray_dir, float t_start, float t_max, float ext_w, float max_ext) {
         float t = t_start;
+        const float inv_max = 1.0f / max_ext;      // contract 2: quotients by the majorant are products with RN(1 / majorant)
         ray_pos = ray_pos + t * ray_dir;
         float tr = 1.0f;
         while (t < t_max) {
-            float t_step = -de_log(rng_next(rng)) / max_ext;
+            float t_step = -de_log_unit(rng_next(rng)) * inv_max;
             ray_pos = ray_pos + t_step * ray_dir;
             t += t_step;
             wk.tracking_steps++;
             if (t >= t_max) break;
             float es = ext_w * get_clouds_density(ray_pos);
-            tr *= 1.0f - es / max_ext;
+            tr *= 1.0f - es * inv_max;
             if (tr < 1e-5f) break;
         }
         return tr;
@@ -511,3 +527,51 @@ __global__ void __launch_bounds__(256) render_kernel(RenderArgs a) {
     }
 }
 
+
+// ray_marcher (pathtracer.py:471-685) as its own kernel: the deterministic 64 x 16 march has fixed trip counts, so one
+// lane = one pixel keeps the wave coherent through the march (only the sphere trace of intersect_land diverges); the
+// gas densities come from the altitude table, the per-pixel RGB sum stays in registers over the launch's samples.
+template <bool CLAMP, int MODE>
+__global__ void __launch_bounds__(256) ray_march_kernel(RenderArgs a) {
+    const int wave = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wave >= a.n_tiles) return;
+    const uint32_t tile = a.tiles[wave];
+    const int lane = threadIdx.x & 63;
+    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (lane & 7);
+    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (lane >> 3);
+    const uint32_t pixel = (uint32_t)(v * a.W + u);
+    const FrameConsts& fc = *a.fc;
+    Work wk = {0, 0, 0, 0, 0};
+    Tracer<CLAMP, true> tr(a, fc, wk);
+    float* px = a.hdr + (size_t)pixel * 3;
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+    if (MODE != 2) { acc_r = px[0]; acc_g = px[1]; acc_b = px[2]; }
+    uint32_t draws = 0;
+    for (int s = 0; s < a.spp_count; ++s) {
+        Rng rng;
+        rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s));
+        int node = 0;
+        if (!a.fixed_wavelength) node = spectrum_node(a.node_val, rng_next(rng));
+        const LambdaNode L = a.nodes[node];
+        vec3 ray_dir = get_cast_dir(rng, fc, a.H, u, v);
+        float sample = tr.ray_marcher(rng, L, fc.cam_pos, ray_dir);
+        vec3 xyz = (sample * v3(L.rx, L.ry, L.rz)) * L.rcp_pdf;
+        vec3 rgb = xyz_to_rgb_d65(xyz);
+        acc_r += rgb.x; acc_g += rgb.y; acc_b += rgb.z;
+        draws += rng.draws;
+        if (MODE == 2) {
+            float* q = a.debug_out + (size_t)pixel * 4;
+            q[0] = sample; q[1] = L.wavelength; q[2] = (float)rng.draws; q[3] = (float)wk.vertices;
+        }
+    }
+    if (MODE != 2) { px[0] = acc_r; px[1] = acc_g; px[2] = acc_b; }
+    if (MODE == 1) {
+        atomicAdd(&a.counters[0], (unsigned long long)a.spp_count);
+        atomicAdd(&a.counters[1], (unsigned long long)wk.taps_r8);
+        atomicAdd(&a.counters[2], (unsigned long long)wk.taps_rgb);
+        atomicAdd(&a.counters[3], (unsigned long long)wk.sphere_steps);
+        atomicAdd(&a.counters[4], (unsigned long long)wk.tracking_steps);
+        atomicAdd(&a.counters[5], (unsigned long long)wk.vertices);
+        atomicAdd(&a.counters[6], (unsigned long long)draws);
+    }
+}

@@ -145,19 +145,21 @@ DE_DEV vec3 get_cast_dir(Rng& rng, const FrameConsts& fc, int H, int u, int v) {
 #ifndef DE_V2_CHUNK
 #define DE_V2_CHUNK 128           // default work items a wave takes from the device-wide counter per atomic (RenderArgs::chunk, set by the host)
 #endif
-#define DE_V2_STASH_FIELDS 36
 #ifndef DE_V2_BLOCK
 // Threads per workgroup.  One wave per workgroup: the waves share nothing but a 1 KB table, and a workgroup's LDS and
 // wave slots are released only when ALL its waves have ended — with 4-wave workgroups the last long paths of a launch
-// kept 3 idle waves' worth of the machine from the next launch (frames in flight, bench.py).  16 x 10 KB = 160 KB LDS per CU.
+// kept 3 idle waves' worth of the machine from the next launch (frames in flight, bench.py).  20 x 7.25 KB of LDS per CU.
 #define DE_V2_BLOCK 64
 #endif
 #ifndef DE_V2_MIN_WAVES
-#define DE_V2_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#define DE_V2_MIN_WAVES 5          // waves per SIMD the register allocator must leave room for (96 VGPRs)
 #endif
 
 // MODE 0: accumulate; 1: accumulate + work counters; 2: trace one sample per pixel into debug_out
 template <bool CLAMP, int MODE>
+#ifdef DE_V2_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(DE_V2_NUM_VGPR)))
+#endif
 __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2(RenderArgs a, const FrameConsts* __restrict__ fcp) {
     using namespace v2;
     // Persistent waves over WORK ITEMS = single samples.  Item w of the launch is sample (w / 64) % spp of lane-pixel
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     float c_ts = 0.0f, c_tm = 0.0f;       // cloud-shell segment of the ray being traced (cloud_limits_of_ray)
     int c_below = 0;
     float d0 = 0.0f, alb = 0.0f, ocean = 0.0f, bathy = 0.0f;
-    float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, maxr = 1.0f, rmaxr = 0.0f;   // rmaxr = 1/maxr when the 3-op division is proven exact, else 0
+    float ext_r = 0.0f, ext_m = 0.0f, ext_o = 0.0f, rmaxr = 0.0f;   // rmaxr = RN(1 / max_ext_rmo): every quotient by the majorant is a product with it (contract 2)
     int state = S_NEW;
     if (a.spp_count <= 0 || a.n_tiles <= 0) state = S_DONE;
 
@@ -212,22 +214,28 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     // stashed path waiting for the same transition, those lanes swap the stashed path in, run the transition
     // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
     // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
-    __shared__ float s_node_val[256];     // spectrum_sample's bisection values: 8 dependent reads per new path, from LDS
-    for (int i = (int)threadIdx.x; i < 256; i += DE_V2_BLOCK) s_node_val[i] = a.node_val[i];
-    __syncthreads();
-    __shared__ uint32_t s_stash[DE_V2_BLOCK / 64][DE_V2_STASH_FIELDS][64];
-    uint32_t* const slot = &s_stash[threadIdx.x >> 6][0][lane];
+    // LDS per wave = the stash only: 29 dwords per lane (7.25 KB) in the production mode, so that 20 one-wave workgroups fit
+    // the CU's 160 KB (5 waves per SIMD; with 96 VGPRs).  spectrum_sample's 255 bisection values are read from global
+    // memory (1 KB, L1-resident; 8 dependent reads per new path) — the kilobyte of LDS they took costs a wave per SIMD.
+    constexpr int STASH_FIELDS = (MODE == 0) ? 29 : 31;
+    __shared__ uint32_t s_stash[STASH_FIELDS][64];
+    uint32_t* const slot = &s_stash[0][lane];
     int stash = 0;                        // 0 empty; 1/2/3 waiting for S_SC_FINISH / S_SURF_SETUP / S_SURF_FINISH; 4 ready to resume
 #define DE_XF(i, var) { const uint32_t tmp_ = slot[(i) * 64]; slot[(i) * 64] = __builtin_bit_cast(uint32_t, var); var = __builtin_bit_cast(decltype(var), tmp_); }
+    // the small integers travel in one dword: state (5 bits) | sc (5) | ev_id (3) | c_below (1) | cnt (8) | node (9)
 #define DE_EXCHANGE_PATH()                                                                                              \
     { DE_XF(0, P.x) DE_XF(1, P.y) DE_XF(2, P.z) DE_XF(3, D.x) DE_XF(4, D.y) DE_XF(5, D.z) DE_XF(6, LD.x) DE_XF(7, LD.y)   \
       DE_XF(8, LD.z) DE_XF(9, N.x) DE_XF(10, N.y) DE_XF(11, N.z) DE_XF(12, thr) DE_XF(13, Ls) DE_XF(14, trg) DE_XF(15, trn) \
       DE_XF(16, alb) DE_XF(17, ocean) DE_XF(18, bathy) DE_XF(19, li) DE_XF(20, atm_x) DE_XF(21, atm_y) DE_XF(22, t)       \
-      DE_XF(23, sc) DE_XF(24, rng.s0) DE_XF(25, rng.s1) DE_XF(26, rng.draws) DE_XF(27, node) DE_XF(28, w) DE_XF(29, ev_id) \
-      DE_XF(30, state) DE_XF(31, path_vertices) DE_XF(32, cnt) DE_XF(33, c_ts) DE_XF(34, c_tm) DE_XF(35, c_below) }
+      DE_XF(23, rng.s0) DE_XF(24, rng.s1) DE_XF(25, w) DE_XF(26, c_ts) DE_XF(27, c_tm)                                     \
+      { uint32_t pk_ = (uint32_t)state | ((uint32_t)sc << 5) | ((uint32_t)ev_id << 10) | ((uint32_t)c_below << 13) |       \
+                       ((uint32_t)cnt << 14) | ((uint32_t)node << 22);                                                     \
+        DE_XF(28, pk_)                                                                                                     \
+        state = (int)(pk_ & 31u); sc = (int)((pk_ >> 5) & 31u); ev_id = (int)((pk_ >> 10) & 7u);                            \
+        c_below = (int)((pk_ >> 13) & 1u); cnt = (int)((pk_ >> 14) & 255u); node = (int)(pk_ >> 22); }                      \
+      if (MODE != 0) { DE_XF(29, rng.draws) DE_XF(30, path_vertices) } }
 #define DE_RELOAD_NODE()                                                                                                \
-    { const LambdaNode& Ln_ = a.nodes[node]; ext_r = Ln_.ext_r; ext_m = Ln_.ext_m; ext_o = Ln_.ext_o; maxr = Ln_.max_ext_rmo; \
-      rmaxr = (Ln_.fast_div != 0.0f) ? Ln_.inv_max_ext_rmo : 0.0f; }
+    { const LambdaNode& Ln_ = a.nodes[node]; ext_r = Ln_.ext_r; ext_m = Ln_.ext_m; ext_o = Ln_.ext_o; rmaxr = Ln_.inv_max_ext_rmo; }
 
     // ---- loop-to-loop glue, executed in place by the lane that finishes a loop (no wait for the transition pass)
     // enter the cloud-shell segment of the current ray: kind 0 = delta tracking of the path ray, 1 / 2 = light sample of a volume / surface vertex
@@ -293,12 +301,11 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         uint32_t tap_q = 0;
         float tap_fx = 0.0f, tap_fy = 0.0f, tap_len = 0.0f;
         bool tap_alive = false, tap_do = false, tap_escaped = false;
+        float dens_r = 0.0f, dens_m = 0.0f, dens_o = 0.0f;   // gas densities at the step's point, fetched from the altitude table
+        bool dens_oob = false;
         // the GAS class runs when enough lanes wait in it (a.gas_thr) or the TAP class is short of lanes
         const bool run_gas = (m_gas != 0ull) && (__popcll(m_gas) >= a.gas_thr || __popcll(m_tap) < 24);
         const bool gasR = gasL && run_gas;
-        // x / maxr takes 3 operations where the device-side proof passed for the lane's wavelength (rmaxr != 0);
-        // otherwise (never with the shipped LUTs) the wave takes the branch with the real divide
-        const bool any_slow_div = run_gas && (__ballot(gasR && rmaxr == 0.0f) != 0ull);
         if (m_tap != 0ull || run_gas) {
             DE_ST_RUN(7, tapL || gasR)
             if (run_gas) DE_ST_RUN(5, gasR)
@@ -309,15 +316,10 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 vec3 Q;
                 tap_alive = true;
                 if (track) {
-                    float maxv, rmaxv;
-                    if (cloud) {
-                        maxv = ((sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT) * DE_CLOUDS_DENSITY;
-                        rmaxv = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
-                    } else { maxv = maxr; rmaxv = rmaxr; }
+                    // free flight: -log(xi) * RN(1 / majorant) (contract 2: the quotient by the majorant as a product)
+                    const float rmaxv = cloud ? ((sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY))) : rmaxr;
                     const float neg_log = -de_log_unit(rng_next(rng));
-                    float t_step = de_div_rc_pinf(neg_log, maxv, rmaxv);
-                    // (the empty asm keeps this a branch: without it the compiler evaluates the divide on every trip and selects)
-                    if (any_slow_div) { asm volatile("" ::: "memory"); if (rmaxv == 0.0f) t_step = neg_log / maxv; }
+                    const float t_step = neg_log * rmaxv;
                     C = C + t_step * W;
                     t += t_step;
                     if (MODE) wk.tracking_steps++;
@@ -334,6 +336,17 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
                 if (tap_alive) {
                     tap_len = length_nr(Q);                        // positions: |Q|^2 ~ 4e13
+                    if (gasR) {
+                        // get_density(get_elevation(pos)) from the altitude table: |Q| lies in [2^22, 2^23), where f32 has a
+                        // spacing of 0.5 m, so h = |Q| - R is an exact multiple of 0.5 and 2h indexes a table that holds
+                        // get_density(h) itself for EVERY possible h below 131 km (dens_table_kernel: the same device function,
+                        // evaluated once per entry).  Issued here so that the load is in flight during the TAP lanes' UV mapping.
+                        const float h2 = de_max(tap_len - DE_PLANET_R, 0.0f) * 2.0f;
+                        const uint32_t di = (uint32_t)(int)h2;
+                        dens_oob = !(h2 < (float)DE_DENS_TABLE_N);
+                        const float* dt = a.dens_table + (size_t)(dens_oob ? 0u : di) * 3u;
+                        dens_r = dt[0]; dens_m = dt[1]; dens_o = dt[2];
+                    }
                     tap_do = tapL && (!cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER));
                     // Escaped ray (generalises SURVEY Q2).  If the rest of the ray stays more than 8 km above every possible
                     // terrain height (its perigee, or its current point once it moves outward), every further SDF value is
@@ -348,8 +361,8 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                         if (peri2 > K * K) { tap_escaped = true; tap_do = false; }
                     }
                     if (tap_do) {
-                        const float inv_len = de_rcp_nr(tap_len);      // RN(1 / len) in 3 operations, then three 5-operation quotients (de_div_y)
-                        const vec3 n = v3(de_div_y(Q.x, tap_len, inv_len), de_div_y(Q.y, tap_len, inv_len), de_div_y(Q.z, tap_len, inv_len));
+                        const float inv_len = de_rcp_nr(tap_len);      // RN(1 / len) in 3 operations; normalized() = v * RN(1 / |v|)
+                        const vec3 n = Q * inv_len;
                         if (MODE) wk.taps_r8++;
                         TexR8 T = a.topo;   // per-lane map select (two maps only in this class)
                         T.data = cloud ? a.clouds.data : a.topo.data;
@@ -369,17 +382,16 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
         // ============================================================ GAS class: densities and collision / transmittance
         if (run_gas) {
             if (gasR) {
-                // numerators: sums of extinction x density, >= 1e-20 inside the atmosphere (Rayleigh density >= 2e-15 up to 110 km)
-                auto gas_div = [&](float x) -> float {
-                    float q = de_div_rc_ng(x, maxr, rmaxr);
-                    if (any_slow_div) { asm volatile("" ::: "memory"); if (rmaxr == 0.0f) q = x / maxr; }
-                    return q;
-                };
+                auto gas_div = [&](float x) -> float { return x * rmaxr; };       // x / max_ext_rmo under contract 2
                 if (!tap_alive) {                                  // t >= t_max: the segment ends without an event
                     if (state == S_DT_G) { rmo_event = EV_NULL; rmo_t = t; ev_id = 0; enter_cloud(0); }
                     else { trg = trn; enter_cloud(state == S_RT_G_V ? 1 : 2); }
                 } else {
-                    vec3 dens = get_density(tap_len - DE_PLANET_R);   // volume.get_density(volume.get_elevation(pos))
+                    vec3 dens = v3(dens_r, dens_m, dens_o);           // volume.get_density(volume.get_elevation(pos)), tabulated
+                    if (__ballot(dens_oob) != 0ull) {                  // above the table (never inside the atmosphere segment): evaluate
+                        asm volatile("" ::: "memory");
+                        if (dens_oob) dens = get_density(tap_len - DE_PLANET_R);
+                    }
                     vec3 es = v3(ext_r, ext_m, ext_o) * dens;
                     float sum = (es.x + es.y) + es.z;
                     if (state == S_DT_G) {
@@ -425,24 +437,23 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     if (tap_do) tex = tap_r8_finish(tap_q, tap_fx, tap_fy);
                     if (cloud) {
                         const float ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
-                        const float maxc = ext_w * DE_CLOUDS_DENSITY;
                         const float rmaxc = (sc > 9) ? (1.0f / (0.02f * DE_CLOUDS_DENSITY)) : (1.0f / (DE_CLOUDS_EXTINCT * DE_CLOUDS_DENSITY));
                         // get_clouds_density, pathtracer.py:48-65
                         float density = 0.0f;
                         if (tap_do) {
-                            float h = DE_DIVC_NG(len - DE_CLOUDS_LOWER, DE_CLOUDS_THICKNESS);   // a multiple of 2^-1 in (0, 6000)
+                            float h = (len - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
                             const float split = 0.2f;
                             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
                         }
                         float es = ext_w * (density * DE_CLOUDS_DENSITY);
                         if (state == S_DT_C) {
                             float rand = rng_next(rng);
-                            if (rand < de_div_rc_ng(es, maxc, rmaxc)) {                 // es is 0 or >= 2e-4
+                            if (rand < es * rmaxc) {
                                 rmo_event |= ((rng_next(rng) < 0.99f) ? EV_SCATTER : EV_ABSORB) << 4;   // cloud event in bits 4-5
                                 state = S_AFTER_DT_C;
                             }
                         } else {
-                            trn *= 1.0f - de_div_rc_ng(es, maxc, rmaxc);
+                            trn *= 1.0f - es * rmaxc;
                             if (trn < 1e-5f) state = (state == S_RT_C_V) ? S_SC_FINISH : S_SURF_FINISH;
                         }
                         // `while t < t_max` at the loop head (pathtracer.py:91,130): implied by the test above unless t is NaN
@@ -730,10 +741,9 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     const uint32_t pixel = (uint32_t)(v * a.W + u);
                     rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
                     node = 0;
-                    if (!a.fixed_wavelength) node = v2::spectrum_node(s_node_val, rng_next(rng));
+                    if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];
-                    ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; maxr = L.max_ext_rmo;
-                    rmaxr = (L.fast_div != 0.0f) ? L.inv_max_ext_rmo : 0.0f;
+                    ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; rmaxr = L.inv_max_ext_rmo;
                     D = v2::get_cast_dir(rng, fc, a.H, u, v);
                     P = fc.cam_pos;
                     thr = 1.0f; Ls = 0.0f; sc = 0;

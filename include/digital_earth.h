@@ -49,7 +49,7 @@ enum {
     DE_FLAG_CLAMP_SAMPLER = 1u << 1,    /* CLAMP_TO_EDGE instead of REPEAT texture addressing */
     DE_FLAG_RAY_MARCHER = 1u << 2,      /* integrate with ray_marcher (pathtracer.py:544-685) instead of path_tracer */
     DE_FLAG_AGX = 1u << 3,              /* display with srgb_transfer(AgX(linear)) — the alternative at renderer.py:356 (lib/AgX.py) — instead of OpenDRT + CRF + gamma */
-    DE_FLAG_NO_FAST_DIVISION = 1u << 4  /* test hook: treat every wavelength as one whose 3-operation division is NOT proven exact, so the kernels take their IEEE-divide fallback; results must not change */
+    DE_FLAG_RESERVED_4 = 1u << 4        /* was a round-1 test hook (IEEE-divide fallback of the tracking loops); ignored since contract 2 */
 };
 
 /* Scalar state of the reference Renderer (renderer.py:18-58), set through its set_* kernels (:224-266). */
@@ -174,7 +174,7 @@ int de_set_kernel_variant(de_ctx* ctx, int variant);
  * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
  * [H][W]) writes 4 floats: radiance, wavelength, number of RNG draws, number of path vertices.
  * de_debug_math: evaluate a deterministic f32 elementary function on the GPU (fn: 0 exp, 1 log, 2 sin, 3 cos,
- * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt, 9 the fast sqrt de_sqrt_nr, 10 the 3-operation a/b, 11 the shared-divisor 5-operation a/b,
+ * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt, 9 the short sqrt de_sqrt_nr, 10 the 3-operation a/b, 11 the shared-divisor 5-operation a/b,
  * 12 log of a random draw de_log_unit, 13 the 3-operation reciprocal de_rcp_nr,
  * 14 exp of a non-positive argument de_exp_nonpos), for bit-exact comparison against the oracle. */
 int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);

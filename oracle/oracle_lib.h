@@ -32,7 +32,8 @@ static inline vec3 operator/(vec3 a, float s) { return vec3(a.x / s, a.y / s, a.
 // Taichi Vector.dot = sum of products, left to right
 static inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 static inline float length(vec3 a) { return sqrt_(dot(a, a)); }
-static inline vec3 normalized(vec3 a) { return a / length(a); }  // v / v.norm(), no epsilon (Appendix B)
+// v.normalized(): no epsilon (Appendix B).  Contract 2: the three quotients by |v| are products with RN(1 / |v|).
+static inline vec3 normalized(vec3 a) { const float inv = 1.0f / length(a); return vec3(a.x * inv, a.y * inv, a.z * inv); }
 static inline vec3 cross(vec3 a, vec3 b) {
     return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
@@ -94,9 +95,11 @@ struct Texture {
         i %= n;
         return i < 0 ? i + n : i;
     }
+    // unorm8 maps: the stored byte as a float (0..255); sample_lod filters the bytes and scales the result by RN(1/255)
+    // (contract 2 — the sampler's own arithmetic is Taichi-internal either way)
     float texel(int i, int j, int ch) const {
         size_t idx = ((size_t)j * w + i) * c + ch;
-        return is_float ? f32[idx] : (float)u8[idx] / 255.0f;
+        return is_float ? f32[idx] : (float)u8[idx];
     }
 };
 struct TapCounters { uint64_t taps_r8 = 0, taps_rgba8 = 0, taps_lut = 0; };
@@ -114,7 +117,8 @@ static inline void sample_lod(const Texture& t, float u, float v, float* out, in
         float t01 = t.texel(i0, j1, ch), t11 = t.texel(i1, j1, ch);
         float a = fma_(t10 - t00, fx, t00);
         float b = fma_(t11 - t01, fx, t01);
-        out[ch] = fma_(b - a, fy, a);
+        float filtered = fma_(b - a, fy, a);
+        out[ch] = t.is_float ? filtered : filtered * OM_INV_255;
     }
     if (t.is_float) g_taps.taps_lut++;
     else if (t.c == 1) g_taps.taps_r8++;
@@ -134,7 +138,8 @@ static inline vec2 rsi(vec3 pos, vec3 dir, float r) {
     return vec2{-b + -discr, -b + discr};
 }
 static inline vec2 sphere_UV_map(vec3 n) {                                            // :25-28
-    return vec2{(atan2_(n.z, -n.x) / (float)M_PI + 1.0f) / 2.0f, asin_(n.y) / (float)M_PI + 0.5f};
+    // (atan2 / pi + 1) / 2  and  asin / pi + 0.5, each as ONE fused multiply-add with RN(1/2pi) / RN(1/pi) (contract 2)
+    return vec2{fma_(atan2_(n.z, -n.x), OM_INV_2PI, 0.5f), fma_(asin_(n.y), OM_INV_PI, 0.5f)};
 }
 static inline float fract(float x) { return x - floorf(x); }
 static inline void sample_sphere_texture(const Texture& t, vec3 pos, float* out, int nch) {  // :38-44, scale = 1

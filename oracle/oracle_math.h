@@ -118,27 +118,31 @@ static inline void sincos_(float x, float* s_out, float* c_out) {
 static inline float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
 static inline float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
 
-// atan2(y, x) in (-pi, pi].  atan2(0, 0) := 0 (signs of zero ignored).
+// ---- contract 2 (round 2): atan2, asin and the log of a random draw are fitted to what the path needs
+// (tools/fit_f32_polys.py fit_c2: 3.5e-7 rad, 6e-8 rad, 2.8e-7 relative) and every quotient by a shared or constant
+// divisor is the product with its correctly rounded reciprocal (1.0f / d is IEEE here).
+static const float OM_INV_PI = (float)(1.0 / M_PI);
+static const float OM_INV_2PI = (float)(0.5 / M_PI);
+static const float OM_INV_255 = (float)(1.0 / 255.0);
+static const float OM_LN2 = 0x1.62e430p-1f;
+
+// atan2(y, x) in (-pi, pi]: ratio = smaller magnitude times the reciprocal of the larger; 0 when both are below 2^-60.
 static inline float atan2_(float y, float x) {
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = (ay > ax) ? ay : ax;
-    float mn = (ay > ax) ? ax : ay;
-    if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;
-    float s = a * a;
-    float p = -0x1.d668cp-10f;
-    p = fma_(p, s, 0x1.65b58ap-7f);
-    p = fma_(p, s, -0x1.feccc6p-6f);
-    p = fma_(p, s, 0x1.dabbfap-5f);
-    p = fma_(p, s, -0x1.582c3cp-4f);
-    p = fma_(p, s, 0x1.c09542p-4f);
-    p = fma_(p, s, -0x1.242104p-3f);
-    p = fma_(p, s, 0x1.9991e4p-3f);
-    p = fma_(p, s, -0x1.55553ep-2f);
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool swap = ay > ax;
+    const float mx = swap ? ay : ax;
+    const float mn = swap ? ax : ay;
+    const float inv = 1.0f / mx;
+    const float a = mn * inv;
+    const float s = a * a;
+    static const float K[6] = {-0x1.5540c2p-2f, 0x1.96cb56p-3f, -0x1.12821cp-3f, 0x1.50f1cep-4f, -0x1.23a7dep-5f, 0x1.e50bcap-8f};
+    float p = K[5];
+    for (int i = 4; i >= 0; --i) p = fma_(p, s, K[i]);
     float r = fma_(a * s, p, a);
-    if (ay > ax) r = OM_PIO2 - r;
+    if (swap) r = OM_PIO2 - r;
     if (x < 0.0f) r = OM_PI - r;
     if (y < 0.0f) r = -r;
+    if (mx < 0x1p-60f) return 0.0f;
     return r;
 }
 
@@ -147,18 +151,32 @@ static inline float asin_(float x) {
     if (x != x) return x;
     float ax = fabsf(x);
     if (ax > 1.0f) ax = 1.0f;
-    bool big = ax > 0.5f;
-    float s = big ? (1.0f - ax) * 0.5f : ax * ax;
-    float t = big ? sqrt_(s) : ax;
-    float p = 0x1.3513acp-5f;
-    p = fma_(p, s, 0x1.d3dfe8p-7f);
-    p = fma_(p, s, 0x1.04f064p-5f);
-    p = fma_(p, s, 0x1.6ca29p-5f);
-    p = fma_(p, s, 0x1.3338d6p-4f);
-    p = fma_(p, s, 0x1.55554cp-3f);
+    const bool big = ax > 0.5f;
+    const float s = big ? (1.0f - ax) * 0.5f : ax * ax;
+    const float t = big ? sqrt_(s) : ax;
+    static const float K[4] = {0x1.554bf8p-3f, 0x1.35737ap-4f, 0x1.409a72p-5f, 0x1.a7813ap-5f};
+    float p = K[3];
+    for (int i = 2; i >= 0; --i) p = fma_(p, s, K[i]);
     float r = fma_(t * s, p, t);
     if (big) r = fma_(-2.0f, r, OM_PIO2);
     return (x < 0.0f) ? -r : r;
+}
+
+// log of a uniform draw x = k * 2^-24 (0 <= k < 2^24).  The significand is brought into [sqrt(1/2), sqrt(2)) by adding
+// bits(1) - bits(sqrt(1/2)) to the representation: the carry into the exponent field does the "halve and increment".
+static inline float log_unit_(float x) {
+    if (x == 0.0f) return -__builtin_inff();
+    const uint32_t shifted = f2u(x) + (0x3f800000u - 0x3f3504f3u);
+    const int e = (int)(shifted >> 23) - 127;
+    const float m = u2f((shifted & 0x007fffffu) + 0x3f3504f3u);
+    const float f = m - 1.0f;
+    static const float K[6] = {0x1.5557bep-2f, -0x1.ffa98cp-3f, 0x1.980734p-3f, -0x1.5ed6f8p-3f, 0x1.4875bep-3f, -0x1.a34a8ap-4f};
+    float p = K[5];
+    for (int i = 4; i >= 0; --i) p = fma_(p, f, K[i]);
+    const float f2 = f * f;
+    float y = (f * f2) * p;
+    y = fma_(-0.5f, f2, y);
+    return fma_((float)e, OM_LN2, f + y);
 }
 
 // a^b for a >= 0 via exp(b*log(a)); exact identities for b == 0 and b == 1.  a < 0 -> NaN.

@@ -54,7 +54,7 @@ static inline float get_clouds_density(const Texture& clouds, vec3 pos) {
     float r = length(pos);
     float density = 0.0f;
     if (r > volume::clouds_lower_limit && r < volume::clouds_upper_limit) {
-        float h = (r - volume::clouds_lower_limit) / volume::clouds_thickness;
+        float h = (r - volume::clouds_lower_limit) * (1.0f / volume::clouds_thickness);   // contract 2: product with RN(1 / thickness)
         float cloud_texture = sample_sphere_texture_r(clouds, pos);
         float column_height = cloud_texture;
         const float split = 0.2f;
@@ -86,22 +86,23 @@ static inline void sample_interaction_delta_tracking(Rng& rng, vec3 ray_pos, vec
                                                      vec4 extinctions, float max_extinction, const Texture& clouds,
                                                      int* event_out, float* t_out, int* id_out) {
     float t = t_start;
+    const float rcp_majorant = 1.0f / max_extinction;   // contract 2: "/ max_extinction" is "* RN(1 / max_extinction)" throughout
     ray_pos = ray_pos + t * ray_dir;
     int interaction_id = 0;
     int event = NULL_EVENT;
     while (t < t_max) {
-        float t_step = -log_(rng.next_f32()) / max_extinction;
+        float t_step = -log_unit_(rng.next_f32()) * rcp_majorant;
         ray_pos = ray_pos + t_step * ray_dir;
         t += t_step;
         g_work.tracking_steps++;
         if (t >= t_max) break;
         vec4 extinction_sample = mul4(extinctions, get_atmos_density(ray_pos, clouds));
         float rand = rng.next_f32();
-        if (rand < sum4(extinction_sample) / max_extinction) {
+        if (rand < sum4(extinction_sample) * rcp_majorant) {
             float cmf = 0.0f;
             while (interaction_id < 3) {
                 cmf += comp4(extinction_sample, interaction_id);
-                if (rand < cmf / max_extinction) break;
+                if (rand < cmf * rcp_majorant) break;
                 interaction_id += 1;
             }
             event = sample_scatter_event(rng, interaction_id) ? SCATTER_EVENT : ABSORB_EVENT;
@@ -114,16 +115,17 @@ static inline void sample_interaction_delta_tracking(Rng& rng, vec3 ray_pos, vec
 static inline float transmittance_ratio_tracking(Rng& rng, vec3 ray_pos, vec3 ray_dir, float t_start, float t_max,
                                                  vec4 extinctions, float max_extinction, const Texture& clouds) {
     float t = t_start;
+    const float rcp_majorant = 1.0f / max_extinction;
     ray_pos = ray_pos + t * ray_dir;
     float transmittance = 1.0f;
     while (t < t_max) {
-        float t_step = -log_(rng.next_f32()) / max_extinction;
+        float t_step = -log_unit_(rng.next_f32()) * rcp_majorant;
         ray_pos = ray_pos + t_step * ray_dir;
         t += t_step;
         g_work.tracking_steps++;
         if (t >= t_max) break;
         vec4 extinction_sample = mul4(extinctions, get_atmos_density(ray_pos, clouds));
-        transmittance *= 1.0f - sum4(extinction_sample) / max_extinction;
+        transmittance *= 1.0f - sum4(extinction_sample) * rcp_majorant;
         if (transmittance < 1e-5f) break;
     }
     return transmittance;

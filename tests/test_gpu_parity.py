@@ -50,6 +50,10 @@ def test_math_bit_exact(Renderer, fid, fn):
     if b is not None:
         b = b.astype(np.float32)
         b[:specials.size] = specials[::-1]
+    if fn == "atan2":     # stated domain of the contract-2 atan2: zero or 2^-60 <= |v| <= 2^60 (components of a unit vector)
+        for v in (a, b):
+            v[~np.isfinite(v)] = 3.0
+            v[(np.abs(v) < 2.0 ** -60) & (v != 0)] = 2.0 ** -59
     got = r.debug_math(fid, a, b)
     x = a[:, None] if b is None else np.stack([a, b], 1)
     want = ob.evaluate(fn, x)[:, 0]
@@ -245,33 +249,17 @@ def test_kernel_variants_agree(Renderer, preset):
 
 
 def test_fast_sqrt_is_correctly_rounded(Renderer):
-    """de_sqrt_nr (v_sqrt_f32 + residual correction) == IEEE sqrt for EVERY significand at both exponent parities."""
+    """de_sqrt_nr (v_rsq_f32 + one coupled Newton step) == IEEE sqrt for EVERY significand at both exponent parities
+    (all 128 exponents of its stated range: tools/exhaustive_math.py)."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
     m = np.arange(1 << 23, dtype=np.uint32)
-    for expo in (127, 128, 172, 173, 97, 110, 111):   # x in [1,2), [2,4), ~4e13 (|pos|^2), ~1e-9, asin's (1-|x|)/2 range
+    for expo in (127, 128, 172, 173, 97, 110, 111, 64, 65, 190, 191):   # x in [1,2), [2,4), ~4e13 (|pos|^2), ~1e-9, asin's (1-|x|)/2 range, the ends of the stated range
         x = ((np.uint32(expo) << np.uint32(23)) | m).view(np.float32)
         got = r.debug_math(9, x)
         want = np.sqrt(x.astype(np.float64)).astype(np.float32)     # correctly rounded: f64 sqrt of an f32 rounds once more, exact for 24-bit inputs
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), expo
     assert r.debug_math(9, np.array([0.0], np.float32))[0] == 0.0
-
-
-def test_ieee_divide_fallback_gives_the_same_frame(Renderer, lut_arrays):
-    """The kernels divide by a wavelength's majorant in 3 operations only where that is proven exact on the device; the
-    fallback (IEEE divide, behind never-taken branches with the shipped LUTs) is forced here and must give the same bits."""
-    from digital_earth_amd import _native
-    def configure(r):
-        r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, True)
-    r, o = _render_pair(Renderer, lut_arrays, 128, 72, 2, configure, dict(texture_source="synthetic", texture_size=(2048, 1024)))
-    g, c, err, same = _compare(r, o, 2)
-    assert same == 1.0
-    r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, False)
-    r.reset_framebuffer(); r.accumulate(2)
-    assert (r.fetch_hdr().view(np.uint32) == g.view(np.uint32)).all()
-    for v in (1, 2):                                   # both kernel variants have the fallback
-        r.set_kernel_variant(v); r.set_flag(_native.DE_FLAG_NO_FAST_DIVISION, True)
-        r.reset_framebuffer(); r.accumulate(2)
-        assert (r.fetch_hdr().view(np.uint32) == g.view(np.uint32)).all()
+    assert np.isnan(r.debug_math(9, np.array([-1.0, np.nan], np.float32))).all()
 
 
 def test_fast_reciprocal_is_correctly_rounded(Renderer):
@@ -300,12 +288,15 @@ def test_exp_of_a_non_positive_argument(Renderer):
 
 
 def test_log_of_a_random_draw(Renderer):
-    """de_log_unit == de_log on every value rng_next can return (k * 2^-24, k = 0 .. 2^24 - 1)."""
+    """de_log_unit (contract 2: integer mantissa reduction, 6-coefficient polynomial) against the oracle's independent
+    statement on EVERY value rng_next can return (k * 2^-24, k = 0 .. 2^24 - 1), and against the f64 logarithm."""
     r = Renderer((16, 8), (0, 1, 0), texture_source="constant")
     x = (np.arange(1 << 24, dtype=np.float64) * 2.0 ** -24).astype(np.float32)
-    a, b = r.debug_math(12, x), r.debug_math(1, x)
+    a = r.debug_math(12, x)
+    b = ob.evaluate("log_unit", x)[:, 0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
     assert np.isneginf(a[0]) and a[1] < -16.6
+    assert np.max(np.abs(a[1:].astype(np.float64) / np.log(x[1:].astype(np.float64)) - 1)) < 6e-7
 
 
 def test_three_operation_division_by_literals(Renderer):

@@ -171,3 +171,39 @@ if __name__ == "__main__":
     fit_cos()
     fit_atan()
     fit_asin()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Contract 2 (round 2): the hot-loop functions, fitted to the accuracy the path needs instead of to 2 ulp.
+#   atan2 / asin feed the sphere UV map: the map coordinate is an f32 in [0, 1] (ulp 6e-8 = 1.3e-3 texel at 21600), so an
+#   angle error of a few 1e-7 rad is at the level of the coordinate's own rounding;
+#   log feeds free-flight distances -log(xi)/majorant: 1e-6 relative is far below the Monte-Carlo noise of any frame.
+def fit_c2(deg_atan=5, deg_asin=4, deg_log=5):
+    x = cheb_nodes(1e-4, 1.0, 8001)
+    s = x * x
+    tgt = (np.arctan(x) - x) / x ** 3
+    B = np.vander(s, deg_atan + 1, increasing=True)
+    c = lawson_fit(B, tgt, x ** 3, iters=200)          # absolute error of the angle
+    c32 = f32(c).astype(np.float64)
+    approx = x + x ** 3 * (B @ c32)
+    print(f"/* C2 atan, {deg_atan + 1} coefficients: max abs err {np.max(np.abs(approx - np.arctan(x))):.3e} rad */")
+    for i, v in enumerate(c32): print(f"#define DE_ATAN2_K{i} {hexf(v)}f")
+    x = cheb_nodes(1e-4, 0.5, 4001)
+    s = x * x
+    tgt = (np.arcsin(x) - x) / x ** 3
+    B = np.vander(s, deg_asin + 1, increasing=True)
+    c = lawson_fit(B, tgt, x ** 3, iters=200)
+    c32 = f32(c).astype(np.float64)
+    approx = x + x ** 3 * (B @ c32)
+    print(f"/* C2 asin, {deg_asin + 1} coefficients: max abs err {np.max(np.abs(approx - np.arcsin(x))):.3e} rad (x2 on the |x| > 0.5 branch) */")
+    for i, v in enumerate(c32): print(f"#define DE_ASIN2_K{i} {hexf(v)}f")
+    a, b = np.sqrt(0.5) - 1, np.sqrt(2.0) - 1
+    x = cheb_nodes(a * 1.0001, b * 1.0001, 6001)
+    x = x[np.abs(x) > 1e-6]
+    tgt = (np.log1p(x) - x + 0.5 * x * x) / x ** 3
+    B = np.vander(x, deg_log + 1, increasing=True)
+    c = lawson_fit(B, tgt, np.abs(x ** 3 / np.log1p(x)), iters=200)
+    c32 = f32(c).astype(np.float64)
+    approx = x - 0.5 * x * x + x ** 3 * (B @ c32)
+    print(f"/* C2 log(1+f), {deg_log + 1} coefficients: max rel err {np.max(np.abs(approx / np.log1p(x) - 1)):.3e} */")
+    for i, v in enumerate(c32): print(f"#define DE_LOG2_K{i} {hexf(v)}f")
