@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdigitalearth_hip.so")
+# DE_LIB_PATH: A/B experiments load another build of the same ABI (tools/ab_build.sh) without touching the product library
+LIB_PATH = os.environ.get("DE_LIB_PATH") or os.path.join(_HERE, "libdigitalearth_hip.so")
 
 
 class DeParams(ctypes.Structure):
@@ -80,6 +81,7 @@ SYMBOLS = {
 }
 
 _lib = None
+ABI_VERSION = 1   # DE_ABI_VERSION of include/digital_earth.h
 
 
 class NativeLibraryError(RuntimeError):
@@ -106,6 +108,8 @@ def load():
             raise NativeLibraryError("%s does not export %s" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    if L.de_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("%s has ABI version %d, this binding expects %d: rebuild it" % (LIB_PATH, L.de_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -18,9 +18,9 @@ __global__ void setup_kernel(SetupArgs s) {
         fc.cam_pos = v3(p.camera_pos[0], p.camera_pos[1], p.camera_pos[2]);
         vec3 look_at = v3(p.look_at[0], p.look_at[1], p.look_at[2]);
         vec3 up = v3(p.up[0], p.up[1], p.up[2]);
-        fc.d = normalized(look_at - fc.cam_pos);                       // renderer.py:272
-        fc.du = normalized(cross(fc.d, up));                           // :276
-        fc.dv = normalized(cross(fc.du, fc.d));                        // :277
+        fc.d = normalized_ieee(look_at - fc.cam_pos);                       // renderer.py:272
+        fc.du = normalized_ieee(cross(fc.d, up));                           // :276
+        fc.dv = normalized_ieee(cross(fc.du, fc.d));                        // :277
         fc.fov = p.fov;
         fc.aspect_ratio = (float)((double)s.W / (double)s.H);          // renderer.py:19
         fc.aspect_scale = p.aspect_scale;

@@ -23,7 +23,11 @@ DE_DEV float length(vec3 a) { return de_sqrt(dot(a, a)); }
 // |a| for positions (|a|^2 ~ 4e13) and other vectors known to be far from the under/overflow ranges
 DE_DEV float length_nr(vec3 a) { return de_sqrt_nr(dot(a, a)); }
 // Vector.normalized() under contract 2: v * RN(1 / |v|) — one reciprocal shared by the three components
-DE_DEV vec3 normalized(vec3 a) { return a * (1.0f / length(a)); }
+DE_DEV vec3 normalized_ieee(vec3 a) { return a * (1.0f / length(a)); }    // any argument (set-up code: camera basis)
+// Every normalisation inside the integrators has |a| = 0 or |a| in [1e-6, 1e9] (directions, positions, SDF differences):
+// the short correctly rounded sqrt and reciprocal apply.  |a| = 0 gives NaN components on both sides (0 * inf there,
+// 0 * NaN here); the reference divides 0 by 0.
+DE_DEV vec3 normalized(vec3 a) { return a * de_rcp_nr(length_nr(a)); }
 DE_DEV vec3 cross(vec3 a, vec3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DE_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 DE_DEV vec3 mix3(vec3 a, vec3 b, float t) { return v3(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
@@ -173,7 +177,9 @@ struct vec2_ { float x, y; };
 DE_DEV vec2_ rsi(vec3 pos, vec3 dir, float r) {
     float b = dot(pos, dir);
     float discr = b * b - dot(pos, pos) + r * r;
-    discr = de_sqrt(discr);
+    // r*r >= 4e13 has a spacing of 2^22: the sum is 0 or at least 2^21 in magnitude (and below 2^64 for |pos| < 4e9 m), inside
+    // the range where the short sqrt is the correctly rounded one; a negative discriminant gives NaN either way
+    discr = de_sqrt_nr(discr);
     vec2_ o;
     o.x = -b + -discr;
     o.y = -b + discr;
@@ -220,7 +226,7 @@ DE_DEV vec3 sample_cone(Rng& rng, float cos_theta_max) {                        
     float u0 = rng_next(rng);
     float u1 = rng_next(rng);
     float cos_theta = (1.0f - u0) + u0 * cos_theta_max;
-    float sin_theta = de_sqrt(1.0f - cos_theta * cos_theta);
+    float sin_theta = de_sqrt_nr(1.0f - cos_theta * cos_theta);      // 0 or in [2^-25, 1]
     float phi = (float)(2.0 * M_PI) * u1;
     float s, c;
     de_sincos(phi, &s, &c);

@@ -79,7 +79,7 @@ DE_DEV void intersect_cloud_limits(vec3 ray_pos, vec3 ray_dir, float land_isecti
 DE_DEV void cloud_limits_of_ray(vec3 ray_pos, vec3 ray_dir, float* t_start_out, float* t_max_out, int* below_out) {
     float t_start = 0.0f, t_max = 0.0f;
     int below = 0;
-    float elevation = length(ray_pos);
+    float elevation = length_nr(ray_pos);
     vec2_ lower = rsi(ray_pos, ray_dir, DE_CLOUDS_LOWER);
     vec2_ upper = rsi(ray_pos, ray_dir, DE_CLOUDS_UPPER);
     if (elevation >= DE_CLOUDS_UPPER) {
@@ -123,10 +123,17 @@ DE_DEV vec3 sample_phase(const FrameConsts& fc, Rng& rng, vec3 ray_dir, int id, 
 DE_DEV float srgb_to_spectrum(const LambdaNode& L, vec3 rgb) {
     return (L.s2s_valid != 0.0f) ? dot(rgb, v3(L.c0, L.c1, L.c2)) : 0.0f;
 }
-DE_DEV int spectrum_node(const float* node_val, float sample) {   // lib/colour.py:21-39
+// lib/colour.py:21-39.  The first DE_V2_LDS_TREE_LEVELS levels of the bisection tree are read from the wave's LDS copy, the
+// rest from global memory (measured: 5 levels 230 ms, 0 levels 232 ms, 7 levels 238 ms per frame — the LDS they take is
+// what limits the waves per CU).
+#ifndef DE_V2_LDS_TREE_LEVELS
+#define DE_V2_LDS_TREE_LEVELS 5
+#endif
+DE_DEV int spectrum_node(const float* lds_val, const float* node_val, float sample) {
     int n = 1;
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
-        float val = node_val[n];
+        float val = (it < DE_V2_LDS_TREE_LEVELS) ? lds_val[n] : node_val[n];
         if (val < sample) n = 2 * n + 1;
         else if (val > sample) n = 2 * n;
         else break;
@@ -214,9 +221,12 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     // stashed path waiting for the same transition, those lanes swap the stashed path in, run the transition
     // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
     // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
-    // LDS per wave = the stash only: 29 dwords per lane (7.25 KB) in the production mode, so that 20 one-wave workgroups fit
-    // the CU's 160 KB (5 waves per SIMD; with 96 VGPRs).  spectrum_sample's 255 bisection values are read from global
-    // memory (1 KB, L1-resident; 8 dependent reads per new path) — the kilobyte of LDS they took costs a wave per SIMD.
+    // LDS per wave = the stash (29 dwords per lane, 7.25 KB, in the production mode) + the first five levels of
+    // spectrum_sample's bisection tree (128 B), so that 20 one-wave workgroups fit the CU's 160 KB (5 waves per SIMD, with
+    // 96 VGPRs).  The tree's last three levels are read from global memory (L1-resident).
+    __shared__ float s_node_val[1 << DE_V2_LDS_TREE_LEVELS];
+    for (int i = lane; i < (1 << DE_V2_LDS_TREE_LEVELS); i += 64) s_node_val[i] = a.node_val[i];
+    __syncthreads();
     constexpr int STASH_FIELDS = (MODE == 0) ? 29 : 31;
     __shared__ uint32_t s_stash[STASH_FIELDS][64];
     uint32_t* const slot = &s_stash[0][lane];
@@ -741,7 +751,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     const uint32_t pixel = (uint32_t)(v * a.W + u);
                     rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
                     node = 0;
-                    if (!a.fixed_wavelength) node = v2::spectrum_node(a.node_val, rng_next(rng));
+                    if (!a.fixed_wavelength) node = v2::spectrum_node(s_node_val, a.node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];
                     ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; rmaxr = L.inv_max_ext_rmo;
                     D = v2::get_cast_dir(rng, fc, a.H, u, v);
