@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                 }
                 if (tap_alive) {
                     tap_len = length_nr(Q);                        // positions: |Q|^2 ~ 4e13
+#ifndef DE_V2_NO_DENS_TABLE
                     if (gasR) {
                         // get_density(get_elevation(pos)) from the altitude table: |Q| lies in [2^22, 2^23), where f32 has a
                         // spacing of 0.5 m, so h = |Q| - R is an exact multiple of 0.5 and 2h indexes a table that holds
@@ -357,6 +358,9 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                         const float* dt = a.dens_table + (size_t)(dens_oob ? 0u : di) * 3u;
                         dens_r = dt[0]; dens_m = dt[1]; dens_o = dt[2];
                     }
+#else
+                    dens_oob = gasR;
+#endif
                     tap_do = tapL && (!cloud || (tap_len > DE_CLOUDS_LOWER && tap_len < DE_CLOUDS_UPPER));
                     // Escaped ray (generalises SURVEY Q2).  If the rest of the ray stays more than 8 km above every possible
                     // terrain height (its perigee, or its current point once it moves outward), every further SDF value is
