@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-world", type=int, default=0, help="1-GPU experiment: render only rank 0's share of an N-rank tile partition (no collective); not a bench line")
     ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
+    ap.add_argument("--integrator", choices=("path_tracer", "ray_marcher"), default="path_tracer",
+                    help="ray_marcher = the reference's alternative integrator (pathtracer.py:471-685, SURVEY §8f-3); not the BASELINE metric")
     ap.add_argument("--tex-size", type=int, nargs=2, default=None, help="override the size of every synthetic map (tests)")
     ap.add_argument("--reduce", choices=("torch", "lib"), default=os.environ.get("DE_REDUCE", "torch"),
                     help="N > 1 collective: torch.distributed (default) or the library's own RCCL communicator (de_comm_init / de_reduce)")
@@ -143,6 +145,7 @@ def main():
         rk = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)
         if args.preset:
             apply_preset(rk, args.preset)
+        rk.set_integrator(args.integrator)
         if k == 0:
             rk.copy_textures()
         else:
@@ -252,7 +255,7 @@ def main():
             with open(prof) as f:
                 pj = json.load(f)
             if pj.get("workload") == "%dx%d_%dspp_q%d" % (W, H, spp, args.tex_quality) and world == 1 and not args.preset \
-                    and not args.tex_size and args.simulate_world <= 1:
+                    and not args.tex_size and args.simulate_world <= 1 and args.integrator == "path_tracer":
                 traffic = pj.get("hbm_bytes_per_launch")
                 traffic_note = pj.get("note", "")
                 valu_insts, lane_util = pj.get("valu_insts_per_launch"), pj.get("valu_lane_utilisation")
@@ -268,14 +271,14 @@ def main():
         "ranks_seen": ranks_seen, "devices_seen": devices_seen,
         "single_frame_ms": single_frame_ms, "single_frame_value": W * H * spp / (single_frame_ms * 1e-3) / 1e6,
         "config": {"workload": "%dx%d, %d spp, full spectral Rayleigh+Mie+O3+clouds, quality-%d synthetic maps%s, %s, "
-                               "BASELINE configs[1]" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
-                                                         args.preset or "default camera"),
+                               "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
+                                                         args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
                    "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
                    "frames_in_flight": len(frames),
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                     "kernel": "render_kernel_v2<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
+                     "kernel": "render_kernel_v2<false, 0>" if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
                      "note": "the path is VALU-issue / divergence bound, not HBM bound (SURVEY §8d): see valu"},
         "valu": {"unit": "see fields", "loop_steps_per_sample": steps_per_sample,

@@ -10,7 +10,7 @@ def read_csvs(pattern):
             rows += list(csv.DictReader(fh))
     return rows
 
-def main(tag, workload="1920x1080_64spp_q2"):
+def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
     root = os.path.join("gpurun_out", "prof_" + tag)
     out = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
     stats = read_csvs(os.path.join(root, "stats", "**", "*kernel_stats.csv"))
@@ -22,7 +22,7 @@ def main(tag, workload="1920x1080_64spp_q2"):
     pmc = defaultdict(list)
     for d in glob.glob(os.path.join(root, "pmc_*")):
         for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")):
-            if "render_kernel" in r.get("Kernel_Name", ""):
+            if "render_kernel" in r.get("Kernel_Name", "") or "ray_march_kernel" in r.get("Kernel_Name", ""):
                 pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     out += ["## PMC counters, render_kernel, mean per launch (64-spp launches only)", "", "| counter | mean per launch | launches |", "|---|---|---|"]
     means = {}
@@ -39,20 +39,23 @@ def main(tag, workload="1920x1080_64spp_q2"):
     if "FETCH_SIZE" in means:
         fetch_kb = means["FETCH_SIZE"]
         wr_kb = means.get("WRITE_SIZE", 0.0)
-        # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads; this kernel's
-        # reads are 4-byte scattered taps (uncalibrated width) -> report raw and x2 as a bracket.
-        out.append("* HBM read  (FETCH_SIZE, KiB->bytes): raw %.4g B, x2-corrected %.4g B per launch" % (fetch_kb * 1024, 2 * fetch_kb * 1024))
-        out.append("* HBM write (WRITE_SIZE): %.4g B per launch" % (wr_kb * 1024))
-        with open(os.path.join("profiles", "hbm_traffic.json"), "w") as f:
-            miss = means.get("TCC_MISS_sum")
-            json.dump({"workload": workload, "hbm_bytes_per_launch": fetch_kb * 1024 + wr_kb * 1024,
-                       "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
-                       "tcc_miss_x_64B": (miss * 64 if miss else None), "profile": tag,
-                       "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"]) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None),
-                       "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), per 64-spp launch. The guide's gfx950 "
-                               "x2 correction is calibrated for wide coalesced streams; this kernel reads scattered 4-byte taps, and "
-                               "raw FETCH_SIZE equals TCC_MISS_sum x 64 B here, so the raw value is reported and x2 kept as an upper bracket"},
-                      f, indent=1)
+        # FETCH_SIZE tallies 64 B per L2->fabric read request; every request moves a 128-byte line — for wide streams (the
+        # guide's gfx950 note) AND for this kernel's scattered dword taps (profiles/r2_fetch_calibration/README.md, measured
+        # with tools/micro/fetch_calib.hip): true read bytes = 2 x FETCH_SIZE.  Infinity-Cache hits are included.
+        out.append("* L2-miss read bytes (2 x FETCH_SIZE, calibrated): %.4g B per launch (raw counter %.4g B)" % (2 * fetch_kb * 1024, fetch_kb * 1024))
+        out.append("* write bytes (WRITE_SIZE): %.4g B per launch" % (wr_kb * 1024))
+        if write_json == "json":
+            with open(os.path.join("profiles", "hbm_traffic.json"), "w") as f:
+                miss = means.get("TCC_MISS_sum")
+                json.dump({"workload": workload, "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + wr_kb * 1024,
+                           "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
+                           "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag,
+                           "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"]) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None),
+                           "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), per 64-spp launch; read bytes = 2 x FETCH_SIZE "
+                                   "(a request moves a 128-B line and is tallied as 64 B — calibrated for scattered dword loads in "
+                                   "profiles/r2_fetch_calibration). L2-miss traffic at the fabric: Infinity-Cache hits (the 3 MB altitude "
+                                   "table) are included, so this over-states HBM traffic"},
+                          f, indent=1)
     os.makedirs("profiles", exist_ok=True)
     with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
