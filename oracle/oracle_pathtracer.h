@@ -215,11 +215,8 @@ static inline vec3 sample_phase(Rng& rng, vec3 ray_dir, int interaction_id, bool
 }
 // :284-313
 struct LandMaterial { vec3 albedo_srgb; float ocean, bathymetry, emissive; };
-static inline LandMaterial get_land_material(const Scene& sc, vec3 pos) {
-    LandMaterial m;
-    m.ocean = sample_sphere_texture_r(*sc.ocean, pos);
-    float a3[3]; sample_sphere_texture(*sc.albedo, pos, a3, 3);
-    vec3 tex(a3[0], a3[1], a3[2]);
+// the colour grade of get_land_material (pathtracer.py:292-306) for an albedo texel and an ocean-mask value
+static inline vec3 grade_land_albedo(vec3 tex, float ocean) {
     vec3 land = mix(lum3(tex), tex, 6.5f);
     float greenery = sqr(land.y / lum(land));
     greenery = smoothstep(1.5f, 1.9f, greenery);
@@ -227,7 +224,13 @@ static inline LandMaterial get_land_material(const Scene& sc, vec3 pos) {
     land = mix(lum3(land), land, 1.4f - greenery * 0.45f);
     land = mix(land, (land * vec3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));   // (a * vec3(..)) / 255.0
     vec3 ocean_albedo = mix(lum3(tex), tex, 0.75f) * 0.9f;
-    m.albedo_srgb = mix(land, ocean_albedo, m.ocean);
+    return mix(land, ocean_albedo, ocean);
+}
+static inline LandMaterial get_land_material(const Scene& sc, vec3 pos) {
+    LandMaterial m;
+    m.ocean = sample_sphere_texture_r(*sc.ocean, pos);
+    float a3[3]; sample_sphere_texture(*sc.albedo, pos, a3, 3);
+    m.albedo_srgb = grade_land_albedo(vec3(a3[0], a3[1], a3[2]), m.ocean);
     m.bathymetry = sample_sphere_texture_r(*sc.bathymetry, pos);
     m.emissive = sample_sphere_texture_r(*sc.emissive, pos);
     return m;
