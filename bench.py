@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--tex-quality", type=int, default=2)
     ap.add_argument("--preset", default=None, help="camera preset file name under digital_earth_amd/data/configs")
     ap.add_argument("--cloud-heavy", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="independent frame contexts alternated step by step (tail overlap)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="independent frame contexts alternated step by step (tail overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-world", type=int, default=0, help="1-GPU experiment: render only rank 0's share of an N-rank tile partition (no collective); not a bench line")
     ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
