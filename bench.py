@@ -292,9 +292,9 @@ def main():
         # The bound that holds is VALU issue.  Instructions per launch = SQ_INSTS_VALU of the committed rocprofv3 --pmc pass
         # of this workload (profiles/); active lanes per instruction = its SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU).
         # Two ceilings are quoted: the guide's 2 cycles per wave64 f32 instruction per SIMD-32 at 2.4 GHz, and the rate
-        # measured on this chip at this kernel's occupancy (tools/micro/dep_latency.hip: 1.11 ns at 4 waves per SIMD).
+        # measured on this chip at this kernel's occupancy (tools/micro/dep_latency.hip: 1.05 ns at 5 waves per SIMD).
         ach_ginst = valu_insts / (avg_kernel_ms * 1e-3) / 1e9
-        peak_meas = 256 * 4 / 1.11
+        peak_meas = 256 * 4 / 1.05
         peak_guide = 256 * 4 * 2.4 / 2.0
         lane_ops_per_sample = valu_insts * 64.0 * lane_util / my_samples
         out["valu"]["issue"] = {"achieved": ach_ginst, "unit": "1e9 wave64 VALU instructions/s",

@@ -294,6 +294,19 @@ DE_DEV vec3 sample_klein_nishina_phase(Rng& rng, vec3 view, float e) {          
     make_orthonormal_basis(view, &tang, &bitang);
     return spherical_direction(sin_theta, cos_theta, phi, tang, bitang, view);
 }
+// The Draine phase function and its analytic CDF inversion below restate formulas that the reference carries under this
+// notice (lib/volume_rendering_models.py:98-120):
+//   SPDX-FileCopyrightText: Copyright (c) <2023> NVIDIA CORPORATION & AFFILIATES. All rights reserved.
+//   SPDX-License-Identifier: MIT
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions: The above copyright notice and
+//   this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 DE_DEV float draine_phase(float c, float g, float a) {                                                 // :121-123
     float d = 1.0f + g * g - 2.0f * g * c;
     return ((1.0f - g * g) * (1.0f + a * c * c)) / (4.0f * (1.0f + (a * (1.0f + 2.0f * g * g)) / 3.0f) * (float)M_PI * (d * de_sqrt(d)));

@@ -246,6 +246,19 @@ static inline vec3 sample_klein_nishina_phase(Rng& rng, vec3 view, float e) {   
 static inline float mie_phase(float c) { return klein_nishina_phase(c, mie_asymmetry); }           // :65-67
 static inline vec3 sample_mie_phase(Rng& rng, vec3 view) { return sample_klein_nishina_phase(rng, view, mie_asymmetry); }  // :69-71
 
+// The Draine phase function and its analytic CDF inversion below restate formulas that the reference carries under this
+// notice (lib/volume_rendering_models.py:98-120):
+//   SPDX-FileCopyrightText: Copyright (c) <2023> NVIDIA CORPORATION & AFFILIATES. All rights reserved.
+//   SPDX-License-Identifier: MIT
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions: The above copyright notice and
+//   this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 // :121-123 (Draine phase; the reference's copy carries NVIDIA's MIT notice at :101-120 — formula restated)
 static inline float draine_phase(float c, float g, float a) {
     float d = 1.0f + g * g - 2.0f * g * c;

@@ -1,8 +1,9 @@
 """The hot kernel's resource budget, checked at compile time (hipcc cross-compiles without a GPU).
 
-render_kernel_v2 is sized to exactly fill a CU: 128 VGPRs -> 4 waves per SIMD, 10 KB of LDS per one-wave workgroup ->
-16 workgroups in 160 KB, and no scratch (a spill inside the wave loop cost 2x in one experiment,
-profiles/experiments/README.md).  A change that silently breaks one of these shows up here, not in a later profile."""
+render_kernel_v2 is sized to exactly fill a CU at 5 waves per SIMD: 96 VGPRs, <= 8 KB of LDS per one-wave workgroup -> 20
+workgroups in 160 KB, and at most a handful of spilled values (loop-invariant constants reloaded in transition code; a
+build whose guards cost 36 spills ran 30 % slower).  A change that silently breaks one of these shows up
+here, not in a later profile."""
 import os
 import re
 import shutil
@@ -30,6 +31,7 @@ def test_render_kernel_v2_resource_budget(tmp_path):
         vgprs = int(re.search(r"VGPRs: (\d+)", body).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", body).group(1))
         occupancy = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", body).group(1))
-        assert scratch == 0, (name, scratch)
-        assert vgprs <= 128 and occupancy >= 4, (name, vgprs, occupancy)
-        assert int(lds) * 16 <= 160 * 1024, (name, lds)
+        spills = int(re.search(r"VGPRs Spill: (\d+)", body).group(1))
+        assert scratch <= 32 and spills <= 8, (name, scratch, spills)
+        assert vgprs <= 96 and occupancy >= 5, (name, vgprs, occupancy)
+        assert int(lds) * 20 <= 160 * 1024, (name, lds)
