@@ -379,11 +379,10 @@ __global__ void math_kernel(int fn, const float* a, const float* b, float* out, 
         case 8: r = de_sqrt(x); break;
         case 9: r = de_sqrt_nr(x); break;
         case 10: r = de_div_rc_ng(x, y, 1.0f / y); break;
-        case 11: r = de_div_y(x, y, 1.0f / y); break;
+        case 11: r = x * de_rcp_nr(y); break;                  // a quotient under contract 2: product with the correctly rounded reciprocal
         case 12: r = de_log_unit(x); break;
         case 13: r = de_rcp_nr(x); break;
         case 14: r = de_exp_nonpos(x); break;
-        case 15: r = de_sqrt_nr(x); break;
         default: r = 0.0f;
     }
     out[k] = r;

@@ -3,8 +3,8 @@
 // Arithmetic contract: every function is a fixed sequence of correctly rounded binary32 operations
 // (+, -, *, /, sqrt, fma) plus floor and bit manipulation, so results do not depend on the device's
 // transcendental units (v_exp_f32 / v_log_f32 / v_sin_f32 are ~1 ulp and unspecified) and are reproducible
-// bit for bit on any IEEE-754 machine.  tests/test_gpu_math.py checks these against the CPU oracle's
-// independent statement of the same sequences.  Coefficients: tools/fit_f32_polys.py.
+// bit for bit on any IEEE-754 machine.  tests/test_gpu_parity.py (test_math_bit_exact, test_log_of_a_random_draw) checks
+// these against the CPU oracle's independent statement of the same sequences.  Coefficients: tools/fit_f32_polys.py.
 //
 // The translation unit must be compiled with -ffp-contract=off (the only fused operations are the explicit
 // de_fma calls) and without fast-math; hipcc's default correctly rounded f32 divide/sqrt is relied upon.
@@ -26,46 +26,17 @@ DE_DEV float de_min(float a, float b) { return (b < a) ? b : a; }
 DE_DEV float de_clamp(float x, float lo, float hi) { return de_min(de_max(x, lo), hi); }
 DE_DEV float de_saturate(float x) { return de_clamp(x, 0.0f, 1.0f); }
 
-// x / c in 3 operations instead of the ~12 of an IEEE divide, for a divisor whose reciprocal rc = RN(1/c) is known.
-// That q below IS the correctly rounded x / c is a property of the divisor: tools/verify_exact_div.c checks it
-// exhaustively (all 2^23 significands) for every literal divisor used in this file set, and setup_kernel checks it on
-// the device for the per-wavelength majorants before enabling it (LambdaNode::fast_div).  Outside
-// 2^-100 <= |x| <= 2^100 (zeros, subnormal residuals, inf, NaN) the real divide runs — a branch no lane normally takes.
-DE_DEV float de_div_rc(float x, float c, float rc) {
-    float q0 = x * rc;
-    float r = de_fma(-q0, c, x);
-    float q = de_fma(r, rc, q0);
-    float ax = de_abs(x);
-    // zero takes the short path too (0 * rc = 0 exactly; only the sign of a -0 quotient differs, which no caller observes)
-    if (__builtin_expect(!(ax >= 0x1p-100f && ax <= 0x1p+100f) && ax != 0.0f, 0)) q = x / c;
-    return q;
-}
-#define DE_DIVC(x, c) de_div_rc((x), (c), 1.0f / (c))
-// Unguarded forms for call sites whose numerator range is known (stated at each use): x is 0 or 2^-100 <= |x| <= 2^100.
+// x / c in 3 operations instead of the ~12 of an IEEE divide, for a LITERAL divisor c with rc = RN(1/c) (the density
+// profiles: 49, 532307548.4168, 1.225, 8136.646).  That q below IS the correctly rounded x / c is a property of the divisor:
+// tools/verify_exact_div.c checks it exhaustively (all 2^23 significands) for every literal used, and
+// tests/test_gpu_parity.py::test_three_operation_division_by_literals on the device.  The numerator must be 0 or in
+// 2^-100 <= |x| <= 2^100 (stated at each use).
 DE_DEV float de_div_rc_ng(float x, float c, float rc) {
     float q0 = x * rc;
     float r = de_fma(-q0, c, x);
     return de_fma(r, rc, q0);
 }
 #define DE_DIVC_NG(x, c) de_div_rc_ng((x), (c), 1.0f / (c))
-// numerator in [2^-100, 2^100] or +inf (the free-flight distance -log(rand) with rand = 0)
-DE_DEV float de_div_rc_pinf(float x, float c, float rc) {
-    float q = de_div_rc_ng(x, c, rc);
-    return (x == __builtin_inff()) ? x : q;
-}
-
-// a / b for a divisor that is shared by several numerators (normalising a vector): y = RN(1/b) is computed once with
-// the real divide, then each quotient takes 5 operations — two rounds of (residual, correction).  After the first round
-// q1 is within 1 ulp of a/b, so by Markstein's theorem (y = RN(1/b), r = a - b*q1 exact in an fma) the second round
-// returns RN(a/b).  Valid away from under/overflow (|a/b|, |a|, |b| in 2^+-60); tests/test_gpu_parity.py::
-// test_shared_divisor_division checks it against the divide on 2^28 operand pairs.
-DE_DEV float de_div_y(float a_, float b, float y) {
-    float q = a_ * y;
-    float r = de_fma(-q, b, a_);
-    q = de_fma(r, y, q);
-    r = de_fma(-q, b, a_);
-    return de_fma(r, y, q);
-}
 
 // sqrt for x = 0 or a normal x in [2^-63, 2^64]: v_rsq_f32 (<= 1 ulp), s = x * y, and one coupled Newton step whose residual
 // x - s*s is exact in an fma.  On gfx950 that IS the correctly rounded root for every significand at every exponent of

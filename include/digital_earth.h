@@ -174,7 +174,7 @@ int de_set_kernel_variant(de_ctx* ctx, int variant);
  * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
  * [H][W]) writes 4 floats: radiance, wavelength, number of RNG draws, number of path vertices.
  * de_debug_math: evaluate a deterministic f32 elementary function on the GPU (fn: 0 exp, 1 log, 2 sin, 3 cos,
- * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt, 9 the short sqrt de_sqrt_nr, 10 the 3-operation a/b, 11 the shared-divisor 5-operation a/b,
+ * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt, 9 the short sqrt de_sqrt_nr, 10 the 3-operation a/b for literal divisors, 11 a * RN(1/b) (contract-2 quotient),
  * 12 log of a random draw de_log_unit, 13 the 3-operation reciprocal de_rcp_nr,
  * 14 exp of a non-positive argument de_exp_nonpos), for bit-exact comparison against the oracle. */
 int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);

@@ -9,7 +9,7 @@
 // of IEEE-754 binary32 operations (+, -, *, /, sqrt, fma — all correctly rounded — plus
 // floor and bit manipulation), so any conforming implementation reproduces it bit for bit.
 // The HIP kernels carry their own implementation of the same sequences
-// (digital_earth_amd/csrc/de_math.h); tests/test_gpu_math.py compares the two bit-exactly.
+// (digital_earth_amd/csrc/de_math.h); tests/test_gpu_parity.py::test_math_bit_exact compares the two bit-exactly.
 //
 // Polynomial coefficients were derived by tools/fit_f32_polys.py (not taken from any libm).
 // Must be compiled with -ffp-contract=off -fno-fast-math -mfma (see oracle/Makefile).
