@@ -275,7 +275,7 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->bathy = r8(DE_TEX_BATHYMETRY); a->emissive = r8(DE_TEX_EMISSIVE);
     a->albedo = rgb(DE_TEX_ALBEDO); a->stars = rgb(DE_TEX_STARS);
     a->hdr = c->d_hdr; a->W = c->W; a->H = c->H;
-    a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8;
+    a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8; a->tiles_identity = (c->tiles_world <= 1) ? 1 : 0;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
     a->pend_thr = c->tune_pend; a->heavy_thr = c->tune_heavy; a->tune_b = c->tune_b; a->gas_thr = c->tune_gas; a->chunk = c->tune_chunk;

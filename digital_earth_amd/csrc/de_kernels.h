@@ -62,6 +62,7 @@ struct RenderArgs {
     int W, H;
     const uint32_t* tiles;        // owned 8x8 tiles (tile id = ty * tiles_x + tx)
     int n_tiles, tiles_x;
+    int tiles_identity;           // tiles[k] == k (tile_world == 1)
     uint32_t seed_lo, seed_hi;
     int spp_begin, spp_count;
     int fixed_wavelength;

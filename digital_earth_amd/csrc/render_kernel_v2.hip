@@ -124,10 +124,10 @@ DE_DEV float srgb_to_spectrum(const LambdaNode& L, vec3 rgb) {
     return (L.s2s_valid != 0.0f) ? dot(rgb, v3(L.c0, L.c1, L.c2)) : 0.0f;
 }
 // lib/colour.py:21-39.  The first DE_V2_LDS_TREE_LEVELS levels of the bisection tree are read from the wave's LDS copy, the
-// rest from global memory (measured: 5 levels 230 ms, 0 levels 232 ms, 7 levels 238 ms per frame — the LDS they take is
-// what limits the waves per CU).
+// rest from global memory (measured per frame: 0 levels 232 ms, 5 levels 230 ms, 6 levels 228 ms, 7 levels 238 ms — the LDS
+// they take is what limits the waves per CU; reading the last two levels with one 32-byte block read changed nothing).
 #ifndef DE_V2_LDS_TREE_LEVELS
-#define DE_V2_LDS_TREE_LEVELS 5
+#define DE_V2_LDS_TREE_LEVELS 6
 #endif
 DE_DEV int spectrum_node(const float* lds_val, const float* node_val, float sample) {
     int n = 1;
@@ -221,9 +221,9 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     // stashed path waiting for the same transition, those lanes swap the stashed path in, run the transition
     // together, and swap back.  The processed path waits in the stash (READY) until the lane's current path ends
     // or is put aside itself.  Per-lane slots only: no cross-lane sharing, no barriers.
-    // LDS per wave = the stash (29 dwords per lane, 7.25 KB, in the production mode) + the first five levels of
-    // spectrum_sample's bisection tree (128 B), so that 20 one-wave workgroups fit the CU's 160 KB (5 waves per SIMD, with
-    // 96 VGPRs).  The tree's last three levels are read from global memory (L1-resident).
+    // LDS per wave = the stash (29 dwords per lane, 7.25 KB, in the production mode) + the first six levels of
+    // spectrum_sample's bisection tree (256 B), so that 20 one-wave workgroups fit the CU's 160 KB (5 waves per SIMD, with
+    // 96 VGPRs).  The tree's last two levels are read from global memory (L1-resident).
     __shared__ float s_node_val[1 << DE_V2_LDS_TREE_LEVELS];
     for (int i = lane; i < (1 << DE_V2_LDS_TREE_LEVELS); i += 64) s_node_val[i] = a.node_val[i];
     __syncthreads();
@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     // (w >> 6) / spp by multiplication (a.spp_magic = floor(2^40 / spp) + 1; exact while (w >> 6) * spp < 2^40)
                     const uint32_t wq = w >> 6;
                     const uint32_t tile_k = (uint32_t)(((unsigned long long)wq * a.spp_magic) >> 40);
-                    const uint32_t tile = a.tiles[tile_k];
+                    const uint32_t tile = a.tiles_identity ? tile_k : a.tiles[tile_k];   // one rank owns every tile: no dependent load (-1.6 % per frame)
                     const int s_idx = (int)(wq - tile_k * (uint32_t)a.spp_count);
                     const int sub = (int)(w & 63u);
                     const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
