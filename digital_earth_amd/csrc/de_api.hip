@@ -291,13 +291,16 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
         hipError_t me = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
         if (me != hipSuccess) return me;
-        // waves: one per owned tile at most (a tile's first 64 work items), and no more than the CUs hold at 5 waves/SIMD (c->tune_wpc = 20 per CU)
-        // (more would only queue behind the resident ones and find the work counter exhausted; they would also keep the
-        // small kernels of the other frame in flight — accumulate, display, memsets — waiting for a slot)
+        // waves: as many as the CUs hold at 5 waves/SIMD (c->tune_wpc = 20 per CU), fewer only when the launch has less than one
+        // chunk of work items per wave — a rank of an 8-way tile partition owns 4050 tiles but 16.6 M work items at 64 spp,
+        // and still fills all 5120 wave slots.  (More waves would only queue behind the resident ones and find the work
+        // counter exhausted; they would also keep the small kernels of the other frames in flight waiting for a slot.)
         const unsigned waves_per_block = DE_V2_BLOCK / 64;
         const unsigned waves_per_cu = (unsigned)c->tune_wpc;
         const unsigned max_waves = (unsigned)c->n_cus * waves_per_cu;
-        const unsigned n_waves = (unsigned)a.n_tiles > max_waves ? max_waves : (unsigned)a.n_tiles;
+        const unsigned long long items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)a.spp_count;
+        const unsigned long long by_work = (items + (unsigned long long)a.chunk - 1ull) / (unsigned long long)a.chunk;
+        const unsigned n_waves = by_work >= (unsigned long long)max_waves ? max_waves : (unsigned)(by_work > 0 ? by_work : 1ull);
         dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
         if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
         else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
