@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -344,7 +345,9 @@ struct Rccl {
 };
 struct UniqueId128 { char internal[128]; };        // ncclUniqueId (rccl.h:43), passed BY VALUE to ncclCommInitRank
 Rccl g_rccl;
+std::mutex g_rccl_mutex;       // contexts of different threads may reach the first use together
 int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.h) return DE_OK;
     void* h = nullptr;
     if (const char* e = getenv("DE_RCCL_PATH")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);

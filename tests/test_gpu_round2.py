@@ -202,6 +202,24 @@ def test_library_communicator_single_rank(Renderer):
     r.comm_destroy()                         # idempotent
 
 
+def test_library_comm_wrapper_single_rank(Renderer):
+    """parallel.LibraryComm (the torch-free host side of de_comm_* / de_reduce, `bench.py --reduce lib`) with one rank: the
+    frame loop reset -> accumulate -> reduce -> display gives the plain renderer's frame."""
+    from digital_earth_amd import parallel
+    kw = dict(texture_source="synthetic", texture_size=(512, 256))
+    a = Renderer((64, 32), (0, 1, 0), seed=2, **kw); a.set_fov(0.4)
+    a.accumulate(2)
+    want_hdr, want_img = a.fetch_hdr(), a.fetch_image()
+    b = Renderer((64, 32), (0, 1, 0), seed=2, **kw); b.set_fov(0.4)
+    lc = parallel.LibraryComm(b, 0, 1, exchange=lambda uid: uid)
+    lc.render_frame(2)
+    assert (b.fetch_hdr().view(np.uint32) == want_hdr.view(np.uint32)).all()
+    assert (b.fetch_image() == want_img).all()
+    lc.render_frame(2)                      # a second frame starts from a reset buffer
+    assert (b.fetch_hdr().view(np.uint32) == want_hdr.view(np.uint32)).all()
+    lc.close()
+
+
 def test_split_launches_give_the_same_bits(Renderer, monkeypatch):
     """de_accumulate splits a request that exceeds render_kernel_v2's per-launch limits; forced here at 3 spp per launch."""
     kw = dict(texture_source="synthetic", texture_size=(1024, 512))
