@@ -186,10 +186,8 @@ DE_DEV vec3 agx_display_transform(const FrameConsts& k, vec3 c) {               
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
-    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (idx >= a.W * a.H) return;
-    const int i = idx % a.W, j = idx / a.W;
+DE_DEV void display_pixel(const DisplayArgs& a, int i, int j, float* o) {
+    const int idx = j * a.W + i;
     const FrameConsts& k = *a.fc;
     float u = 1.0f * (float)i / (float)a.W;                            // renderer.py:349-350
     float v = 1.0f * (float)j / (float)a.H;
@@ -198,7 +196,6 @@ __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
     const float* px = a.hdr + (size_t)idx * 3;
     float samples = (float)a.samples;
     vec3 linear = v3(px[0] / samples, px[1] / samples, px[2] / samples) * darken * k.exposure_scale;   // :355
-    float* o = a.image + ((size_t)i * a.H + j) * 3;                    // (W, H, 3)
     if (k.use_agx) {                                                   // :356: srgb_transfer(agx.display_transform(linear))
         vec3 ax = agx_display_transform(k, linear);
         o[0] = srgb_transfer1(ax.x); o[1] = srgb_transfer1(ax.y); o[2] = srgb_transfer1(ax.z);
@@ -214,6 +211,31 @@ __global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
     vec3 cam = v3(de_clamp(red, 0.0f, 1.0f), de_clamp(green, 0.0f, 1.0f), de_clamp(blue, 0.0f, 1.0f));
     vec3 g = v3(de_pow(cam.x, k.gamma), de_pow(cam.y, k.gamma), de_pow(cam.z, k.gamma));   // :360
     o[0] = srgb_transfer1(g.x); o[1] = srgb_transfer1(g.y); o[2] = srgb_transfer1(g.z);    // :362-365
+}
+
+// One 256-thread block = one 32 x 32 pixel tile.  The accumulation buffer is [H][W][3] (pixels of a row contiguous), the
+// image (W, H, 3) like the reference field (pixels of a COLUMN contiguous): each thread transforms 4 pixels read along rows
+// and stages them in LDS; the tile is then written out along columns, so both sides move whole lines.
+__global__ void __launch_bounds__(256) display_kernel(DisplayArgs a) {
+    __shared__ float tile[32][32 * 3 + 1];
+    const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;      // 32 x 8 threads
+    const int i0 = (int)blockIdx.x * 32, j0 = (int)blockIdx.y * 32;
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + tx, j = j0 + ty + 8 * r;
+        if (i < a.W && j < a.H) {
+            float o[3];
+            display_pixel(a, i, j, o);
+            tile[ty + 8 * r][tx * 3 + 0] = o[0]; tile[ty + 8 * r][tx * 3 + 1] = o[1]; tile[ty + 8 * r][tx * 3 + 2] = o[2];
+        }
+    }
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;                        // consecutive threads: consecutive j of one column i
+        if (i < a.W && j < a.H) {
+            float* o = a.image + ((size_t)i * a.H + j) * 3;
+            o[0] = tile[tx][(ty + 8 * r) * 3 + 0]; o[1] = tile[tx][(ty + 8 * r) * 3 + 1]; o[2] = tile[tx][(ty + 8 * r) * 3 + 2];
+        }
+    }
 }
 
 // Second half of render_kernel_v2: add the samples of every owned pixel to the HDR buffer IN SAMPLE ORDER
@@ -241,12 +263,22 @@ __global__ void __launch_bounds__(256) accumulate_kernel(RenderArgs a) {
     px[0] = acc_r; px[1] = acc_g; px[2] = acc_b;
 }
 
-// (W, H, 3) view of the [H][W][3] accumulation buffer
-__global__ void hdr_transpose_kernel(const float* hdr, float* out, int W, int H) {
-    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (idx >= W * H) return;
-    const int i = idx % W, j = idx / W;
-    for (int c = 0; c < 3; ++c) out[((size_t)i * H + j) * 3 + c] = hdr[(size_t)idx * 3 + c];
+// (W, H, 3) view of the [H][W][3] accumulation buffer: 32 x 32 tiles through LDS, contiguous on both sides
+__global__ void __launch_bounds__(256) hdr_transpose_kernel(const float* hdr, float* out, int W, int H) {
+    __shared__ float tile[32][32 * 3 + 1];
+    const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;
+    const int i0 = (int)blockIdx.x * 32, j0 = (int)blockIdx.y * 32;
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + tx, j = j0 + ty + 8 * r;
+        if (i < W && j < H)
+            for (int c = 0; c < 3; ++c) tile[ty + 8 * r][tx * 3 + c] = hdr[((size_t)j * W + i) * 3 + c];
+    }
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < W && j < H)
+            for (int c = 0; c < 3; ++c) out[((size_t)i * H + j) * 3 + c] = tile[tx][(ty + 8 * r) * 3 + c];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ texture packing

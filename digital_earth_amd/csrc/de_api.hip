@@ -640,7 +640,7 @@ int de_render_to_image(de_ctx* c, const float** device_image) {
     d.crf.data = c->d_crf; d.crf.w = 1024; d.crf.h = c->n_crf;
     d.W = c->W; d.H = c->H; d.samples = c->current_spp; d.clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) ? 1 : 0;
     size_t npx = (size_t)c->W * c->H;
-    hipLaunchKernelGGL(display_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, d);
+    hipLaunchKernelGGL(display_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, d);
     HIP_TRY(hipGetLastError());
     if (device_image) *device_image = c->d_image;
     return DE_OK;
@@ -657,7 +657,7 @@ int de_fetch_hdr(de_ctx* c, float* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     size_t npx = (size_t)c->W * c->H;
-    hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
+    hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
     HIP_TRY(hipGetLastError());
     return copy_out(c, out, c->d_scratch);
 }
