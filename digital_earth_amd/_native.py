@@ -48,6 +48,7 @@ SYMBOLS = {
     "de_upload_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "de_generate_texture": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int]),
     "de_share_textures": (ctypes.c_int, [_P, _P]),
+    "de_trim_textures": (ctypes.c_int, [_P]),
     "de_download_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint64]),
     "de_texture_info": (ctypes.c_int, [_P, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3),
     "de_upload_luts": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int]),

@@ -187,6 +187,7 @@ namespace {
 int ensure_packed(de_ctx* c, int slot, bool clamp) {
     DevTexture& t = c->tex[slot];
     if (t.packed_clamp == (clamp ? 1 : 0)) return DE_OK;
+    if (!t.linear) return fail(DE_ERR_STATE, "the sampler address mode cannot change after de_trim_textures released the as-uploaded maps: upload or generate them again");
     if (t.borrowed) return fail(DE_ERR_STATE, "a shared texture keeps its owner's address mode: set DE_FLAG_CLAMP_SAMPLER on the owner and render there once, then share again");
     if (t.ch == 1) {
         dim3 grid((unsigned)((t.w + 255) / 256), (unsigned)t.h);
@@ -513,9 +514,30 @@ int de_share_textures(de_ctx* dst, de_ctx* src) {
     return DE_OK;
 }
 
+int de_trim_textures(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    for (int i = 0; i < DE_TEX_COUNT; ++i) {
+        DevTexture& t = c->tex[i];
+        if (!t.set || t.borrowed || !t.linear) continue;
+        int rc = ensure_packed(c, i, clamp);          // the packed copy must exist before its source goes
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < DE_TEX_COUNT; ++i) {
+        DevTexture& t = c->tex[i];
+        if (!t.set || t.borrowed || !t.linear) continue;
+        hipFree(t.linear);
+        t.linear = nullptr;
+    }
+    return DE_OK;
+}
+
 int de_download_texture(de_ctx* c, int slot, uint8_t* out, uint64_t out_bytes) {
     if (!c || slot < 0 || slot >= DE_TEX_COUNT || !out || !c->tex[slot].set) return fail(DE_ERR_INVALID, "texture not set");
     const DevTexture& t = c->tex[slot];
+    if (!t.linear) return fail(DE_ERR_STATE, "the as-uploaded copy of this map was released (de_trim_textures)");
     size_t n = (size_t)t.w * t.h * t.ch;
     if (out_bytes < n) return fail(DE_ERR_INVALID, "output buffer too small");
     HIP_TRY(hipSetDevice(c->device));

@@ -224,6 +224,12 @@ class Renderer:
         self._lender = other
         self._textures_copied = True
 
+    def trim_textures(self):
+        """Free the as-uploaded copies of the maps (2.1 GB at quality 2); the kernels keep their packed copies."""
+        if not self._textures_copied:
+            self.copy_textures()
+        check(self._lib.de_trim_textures(self._h))
+
     def download_texture(self, slot):
         w, h, ch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.de_texture_info(self._h, slot, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)))

@@ -103,6 +103,10 @@ int de_generate_texture(de_ctx* ctx, int slot, int width, int height, uint32_t s
  * flight, a second view of the same Earth: 9 GB at quality 2).  Read-only borrowing: `src` must outlive `dst` or `dst`
  * must upload / generate maps of its own before `src` is destroyed; the borrowed maps keep `src`'s address mode. */
 int de_share_textures(de_ctx* dst, de_ctx* src);
+/* Release the as-uploaded (linear u8) copies of the maps, 2.1 GB at quality 2, keeping the packed copies the kernels read.
+ * Afterwards de_download_texture and a change of the sampler address mode fail with DE_ERR_STATE until the maps are
+ * uploaded or generated again. */
+int de_trim_textures(de_ctx* ctx);
 /* Read a map back as uploaded (row-major, `channels` bytes per texel) — lets tests hand the same texels to the oracle. */
 int de_download_texture(de_ctx* ctx, int slot, uint8_t* out, uint64_t out_bytes);
 int de_texture_info(de_ctx* ctx, int slot, int* width, int* height, int* channels);

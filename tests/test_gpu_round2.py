@@ -179,6 +179,24 @@ def test_shared_maps_between_contexts(Renderer):
     b.close(); a.close()
 
 
+def test_trim_textures_keeps_rendering(Renderer):
+    from digital_earth_amd._native import DigitalEarthError
+    from digital_earth_amd import _native
+    r = Renderer((64, 32), (0, 1, 0), texture_source="synthetic", texture_size=(512, 256), seed=1); r.set_fov(0.4)
+    r.accumulate(2)
+    want = r.fetch_hdr()
+    r.trim_textures()
+    r.reset_framebuffer(); r.accumulate(2)
+    assert (r.fetch_hdr().view(np.uint32) == want.view(np.uint32)).all()
+    with pytest.raises(DigitalEarthError):
+        r.download_texture(1)
+    r.set_flag(_native.DE_FLAG_CLAMP_SAMPLER, True)
+    with pytest.raises(DigitalEarthError):
+        r.accumulate(1)                       # repacking for another address mode needs the released copies
+    r.copy_textures()                         # generating them again makes the context whole
+    r.accumulate(1)
+
+
 def test_library_communicator_single_rank(Renderer):
     """de_comm_unique_id / de_comm_init / de_reduce / de_comm_destroy with a 1-rank RCCL communicator: binds librccl at
     run time and runs ncclReduce in place on the context's stream (a 1-GPU box cannot hold two RCCL ranks)."""
