@@ -179,6 +179,11 @@ def main():
     n_r8 = cnt["taps_r8"] / max(cnt["samples"], 1)
     n_rgb = cnt["taps_rgb8"] / max(cnt["samples"], 1)
 
+    # every context in flight allocates its per-sample buffer at its first full-size launch: prime them all (untimed), whatever
+    # --warmup says, so that no allocation can fall into the timed region
+    for f in frames:
+        f.render_frame(spp)
+    barrier()
     for i in range(args.warmup):
         frames[i % len(frames)].render_frame(spp)
     barrier()
