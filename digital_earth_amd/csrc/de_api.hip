@@ -145,7 +145,7 @@ struct de_ctx {
     de_params p;
     bool params_dirty = true;     // FrameConsts must be rebuilt (any scalar parameter, the topography width)
     bool nodes_dirty = true;      // the wavelength table must be rebuilt (LUTs, address mode, fixed wavelength)
-    int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 10, tune_chunk = 128, tune_wpc = 20, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
+    int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 6, tune_chunk = 128, tune_wpc = 20, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
