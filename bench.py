@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything initialises HIP (torch included): enough hardware queues for the library's launch slots to run side by side
+# (digital_earth_amd/_native.py sets the same default when it loads the library first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -36,7 +39,9 @@ def parse():
     ap.add_argument("--tex-quality", type=int, default=2)
     ap.add_argument("--preset", default=None, help="camera preset file name under digital_earth_amd/data/configs")
     ap.add_argument("--cloud-heavy", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="independent frame contexts alternated step by step (tail overlap)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="independent frame contexts alternated step by step.  Default 1: since round 3 the library overlaps the "
+                         "launches of ONE context itself (launch slots, de_accumulate in include/digital_earth.h); >1 is the round-2 scheme")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-world", type=int, default=0, help="1-GPU experiment: render only rank 0's share of an N-rank tile partition (no collective); not a bench line")
     ap.add_argument("--cpu-spp", type=int, default=8, help="upper bound on the spp of the bounded CPU-baseline sample (~15 s)")
@@ -56,7 +61,27 @@ def apply_preset(r, name):
     cfg.apply(r)
 
 
-def cpu_baseline(r, args):
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None when the file does not say."""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return len(cores) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(r, args, maps):
     """The CPU oracle (a port of the reference algorithm, NOT Taichi's ti.cpu) on a bounded sample of the same workload:
     the full frame at --cpu-spp samples per pixel, same maps / camera / seed, all host threads."""
     import ctypes
@@ -67,7 +92,7 @@ def cpu_baseline(r, args):
     names, crf = luts.load_crfs()
     o.upload_luts(luts.load_cie(), luts.load_srgb2spec(), luts.load_o3(), crf)
     for s in range(7):
-        o.upload_texture(s, r.download_texture(s))
+        o.upload_texture(s, maps[s])
     p = ob.DeParams()
     ctypes.memmove(ctypes.byref(p), ctypes.byref(r._params), ctypes.sizeof(p))
     o.set_params(p)
@@ -81,7 +106,10 @@ def cpu_baseline(r, args):
     dt = time.perf_counter() - t0
     args.cpu_spp = 1 + extra
     n = W * H * args.cpu_spp
-    out = {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": o.threads, "kind": "port",
+    cores = physical_cores()
+    out = {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores if cores else o.threads, "threads": o.threads, "kind": "port",
+           "cores_note": "physical cores of the host (/proc/cpuinfo); `threads` = OpenMP threads actually used (all hardware threads)" if cores
+                         else "physical core count unavailable: `cores` = OpenMP threads used",
            "sample": "full %dx%d frame at %d spp (%d samples, %.1f s), same maps/camera/seed; C++ restatement of the "
                      "reference algorithm (oracle/), OpenMP over 16x8 pixel blocks" % (W, H, args.cpu_spp, n, dt)}
     # the same sample doubles as a full-size parity check of the GPU image (1 spp at matched seed)
@@ -161,6 +189,12 @@ def main():
         if args.simulate_world > 1 and world == 1:
             rk.set_tile_partition(0, args.simulate_world)
     r, frame = frames[0].r, frames[0]
+    # the CPU-baseline leg (after the timed region) needs the maps as uploaded: take them to the host now, then release the
+    # 2.1 GB of as-uploaded device copies — the kernels read the packed copies only
+    maps = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        maps = [r.download_texture(s) for s in range(7)]
+    r.trim_textures()
 
     def barrier():
         for f in frames:
@@ -263,10 +297,17 @@ def main():
                 pj = json.load(f)
             if pj.get("workload") == "%dx%d_%dspp_q%d" % (W, H, spp, args.tex_quality) and world == 1 and not args.preset \
                     and not args.tex_size and args.simulate_world <= 1 and args.integrator == "path_tracer":
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_note = pj.get("note", "")
-                valu_insts, lane_util = pj.get("valu_insts_per_launch"), pj.get("valu_lane_utilisation")
-                prof_name = pj.get("profile")
+                # the counters belong to the kernel build that was profiled: refuse them when this run's launch duration is
+                # not the profile's (+-3 %) — a changed kernel with an unrefreshed profile must not carry stale numbers
+                prof_ms = pj.get("kernel_ms")
+                if prof_ms and abs(avg_kernel_ms - prof_ms) <= 0.03 * prof_ms:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_note = pj.get("note", "")
+                    valu_insts, lane_util = pj.get("valu_insts_per_launch"), pj.get("valu_lane_utilisation")
+                    prof_name = pj.get("profile")
+                else:
+                    traffic_note = ("profiles/hbm_traffic.json (profile %s) is for a launch of %s ms, this run measured %.1f ms: counters "
+                                    "withheld as stale" % (pj.get("profile"), prof_ms, avg_kernel_ms))
         except Exception:
             pass
 
@@ -314,7 +355,7 @@ def main():
         out["valu"]["frac"] = out["valu"]["achieved_tlaneops"] / out["valu"]["peak_tlaneops"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, o = cpu_baseline(r, args)
+        base, o = cpu_baseline(r, args, maps)
         out["cpu_baseline"] = base
         # full-size parity at matched seed: GPU frame vs the CPU frame just computed
         r.set_tile_partition(0, 1)

@@ -28,6 +28,17 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(DE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+#define DE_MAX_SLOTS 8
+struct LaunchSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;           // recorded after the slot's latest accumulate_kernel
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    uint2* contrib = nullptr;            // per-sample (radiance, wavelength node) records of the launch in this slot
+    size_t contrib_items = 0;
+    bool pending = false;                // `done` has not been waited for by the context stream yet
+    uint64_t seen_render = 0, seen_hdr = 0;
+};
+
 struct DevTexture {
     int w = 0, h = 0, ch = 0;
     uint8_t* linear = nullptr;    // as uploaded: [h][w][ch]
@@ -146,9 +157,19 @@ struct de_ctx {
     bool params_dirty = true;     // FrameConsts must be rebuilt (any scalar parameter, the topography width)
     bool nodes_dirty = true;      // the wavelength table must be rebuilt (LUTs, address mode, fixed wavelength)
     int tune_pend = 18, tune_heavy = 13, tune_b = 24, tune_gas = 6, tune_chunk = 128, tune_wpc = 20, tune_max_spp = 0;   // DE_V2_* overrides, read once in de_create
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the context stream: everything except the render launches (reset, display, fetch, reduce, uploads)
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Launch slots (round 3): de_accumulate does not launch on the context stream.  Launch k goes to slot k % n_slots, which has
+    // its own stream, work counter and contribution buffer, so that consecutive launches overlap — the next render kernel
+    // fills the machine while the last long paths of the previous one drain (the reference's interactive loop is
+    // accumulate() x 1 per frame, earth_viewer.py:241-243).  The accumulate_kernels, which read-modify-write the HDR buffer,
+    // are chained with events in launch order, so the per-pixel sums keep their association.  The context stream waits for
+    // the slots lazily (join_slots) before anything that reads or writes the HDR buffer or rewrites what a launch reads.
+    LaunchSlot slot[DE_MAX_SLOTS];
+    int n_slots = 8, big_slots = 3, next_slot = 0, last_slot = -1;   // launches with > 96 MB of records cycle through the first big_slots only
+    hipEvent_t ev_main = nullptr;   // last state of the context stream the slots may have to wait for
+    uint64_t gen_render = 1, gen_hdr = 1, rec_render = 0, rec_hdr = 0;   // generations of context-stream work that launches depend on
+    int t0_slot = -1, t1_slot = -1;
     bool timing_valid = false;
     DevTexture tex[DE_TEX_COUNT];
     float* d_cie = nullptr;      // 441 x 2 x 3 (f16-quantised)
@@ -169,10 +190,8 @@ struct de_ctx {
     uint32_t* d_tiles = nullptr;
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_work_counter = nullptr;
+    uint32_t* d_work_counter = nullptr;   // 16 dwords per launch slot
     float* d_dens_table = nullptr;   // get_density by altitude index (DE_DENS_TABLE_N x 3)
-    uint2* d_contrib = nullptr;  // v2 per-sample contributions
-    size_t contrib_items = 0;
     int n_cus = 256;
     bool count = false;
     de_counters counters;
@@ -180,15 +199,45 @@ struct de_ctx {
     void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
     int comm_rank = 0, comm_world = 1;
     int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip)
+    de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
+    int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked
 };
 
 namespace {
 
+// The context stream waits (on the device; the host does not block) for every launch issued so far.  Called before anything on
+// the context stream that touches the HDR buffer or rewrites data a render launch reads.
+int join_slots(de_ctx* c) {
+    for (int i = 0; i < c->n_slots; ++i) {
+        LaunchSlot& s = c->slot[i];
+        if (!s.pending) continue;
+        HIP_TRY(hipStreamWaitEvent(c->stream, s.done, 0));
+        s.pending = false;
+    }
+    return DE_OK;
+}
+// context-stream work that the next launches must be ordered after: what a render kernel reads / the HDR buffer
+void touched_render_inputs(de_ctx* c) { c->gen_render++; }
+void touched_hdr(de_ctx* c) { c->gen_hdr++; }
+int sync_all(de_ctx* c) {
+    for (int i = 0; i < c->n_slots; ++i)
+        if (c->slot[i].stream) HIP_TRY(hipStreamSynchronize(c->slot[i].stream));
+    for (int i = 0; i < c->n_slots; ++i) c->slot[i].pending = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+void release_loan(de_ctx* c) {
+    if (c->lender) { c->lender->loans--; c->lender = nullptr; }
+}
+
 int ensure_packed(de_ctx* c, int slot, bool clamp) {
     DevTexture& t = c->tex[slot];
     if (t.packed_clamp == (clamp ? 1 : 0)) return DE_OK;
-    if (!t.linear) return fail(DE_ERR_STATE, "the sampler address mode cannot change after de_trim_textures released the as-uploaded maps: upload or generate them again");
     if (t.borrowed) return fail(DE_ERR_STATE, "a shared texture keeps its owner's address mode: set DE_FLAG_CLAMP_SAMPLER on the owner and render there once, then share again");
+    if (!t.linear) return fail(DE_ERR_STATE, "the sampler address mode cannot change after de_trim_textures released the as-uploaded maps: upload or generate them again");
+    if (c->loans > 0 && t.packed_clamp != -1) return fail(DE_ERR_STATE, "the maps are lent to another context (de_share_textures): they cannot be repacked for another address mode until every borrower is destroyed or holds maps of its own");
+    { int rc = join_slots(c); if (rc) return rc; }
+    touched_render_inputs(c);
     if (t.ch == 1) {
         dim3 grid((unsigned)((t.w + 255) / 256), (unsigned)t.h);
         hipLaunchKernelGGL(pack_r8_kernel, grid, dim3(256), 0, c->stream, t.linear, t.packed, t.w, t.h, t.tiles_x, clamp ? 1 : 0);
@@ -203,9 +252,17 @@ int ensure_packed(de_ctx* c, int slot, bool clamp) {
 
 int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
     DevTexture& t = c->tex[slot];
+    if (c->loans > 0) return fail(DE_ERR_STATE, "the maps are lent to another context (de_share_textures): destroy the borrowers, or give them maps of their own, before replacing a map");
+    { int rc = sync_all(c); if (rc) return rc; }      // no launch may still read the map that is being replaced
     if (t.linear && !t.borrowed) hipFree(t.linear);
     if (t.packed && !t.borrowed) hipFree(t.packed);
     t.linear = nullptr; t.packed = nullptr; t.borrowed = false;
+    {   // a borrower that now owns every map again gives the loan back
+        bool any = false;
+        for (int i = 0; i < DE_TEX_COUNT; ++i) any = any || (i != slot && c->tex[i].borrowed);
+        if (!any && !c->luts_borrowed) release_loan(c);
+    }
+    touched_render_inputs(c);
     t.w = w; t.h = h; t.ch = ch; t.set = false; t.packed_clamp = -1;
     HIP_TRY(hipMalloc(&t.linear, (size_t)w * h * ch));
     if (ch == 1) {
@@ -220,6 +277,8 @@ int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
 
 int run_setup(de_ctx* c) {
     if (!c->params_dirty && !c->nodes_dirty) return DE_OK;
+    { int rc = join_slots(c); if (rc) return rc; }    // launches in flight still read the tables this rewrites
+    touched_render_inputs(c);
     SetupArgs s;
     s.p = c->p;
     opendrt_consts(&s.drt[0], &s.drt[1], &s.drt[2], &s.drt[3], &s.drt[4], &s.drt[5]);
@@ -241,6 +300,8 @@ int run_setup(de_ctx* c) {
 
 int build_tiles(de_ctx* c, int rank, int world) {
     if (c->tiles_rank == rank && c->tiles_world == world && c->d_tiles) return DE_OK;
+    { int rc = sync_all(c); if (rc) return rc; }      // launches in flight read the tile list
+    touched_render_inputs(c);
     const int tx = c->W / 8, ty = c->H / 8;
     std::vector<uint32_t> tiles;
     tiles.reserve((size_t)tx * ty / world + tx);
@@ -279,24 +340,27 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->hdr = c->d_hdr; a->W = c->W; a->H = c->H;
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8; a->tiles_identity = (c->tiles_world <= 1) ? 1 : 0;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
-    a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;
+    a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;   // work_counter / contrib: per launch slot, set by the caller
     a->pend_thr = c->tune_pend; a->heavy_thr = c->tune_heavy; a->tune_b = c->tune_b; a->gas_thr = c->tune_gas; a->chunk = c->tune_chunk;
     return DE_OK;
 }
 
-template <int MODE>
-hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
+// One launch on `stream`.  v2 (the default path tracer): render_kernel_v2 writes the per-sample records, then — after `pre_acc`
+// has made the stream wait for the previous launch's accumulate_kernel and for context-stream work on the HDR buffer — accumulate_kernel
+// adds them to the HDR buffer.  The other kernels read-modify-write the HDR buffer themselves: `pre_acc` runs before them.
+template <int MODE, typename PreAcc>
+hipError_t launch_render(de_ctx* c, const RenderArgs& a, hipStream_t stream, PreAcc pre_acc) {
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
     if (!march && c->kernel_variant == 2) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
-        hipError_t me = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+        hipError_t me = hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), stream);
         if (me != hipSuccess) return me;
         // waves: as many as the CUs hold at 5 waves/SIMD (c->tune_wpc = 20 per CU), fewer only when the launch has less than one
         // chunk of work items per wave — a rank of an 8-way tile partition owns 4050 tiles but 16.6 M work items at 64 spp,
         // and still fills all 5120 wave slots.  (More waves would only queue behind the resident ones and find the work
-        // counter exhausted; they would also keep the small kernels of the other frames in flight waiting for a slot.)
+        // counter exhausted; they would also keep the small kernels of the other launches in flight waiting for a slot.)
         const unsigned waves_per_block = DE_V2_BLOCK / 64;
         const unsigned waves_per_cu = (unsigned)c->tune_wpc;
         const unsigned max_waves = (unsigned)c->n_cus * waves_per_cu;
@@ -304,16 +368,22 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a) {
         const unsigned long long by_work = (items + (unsigned long long)a.chunk - 1ull) / (unsigned long long)a.chunk;
         const unsigned n_waves = by_work >= (unsigned long long)max_waves ? max_waves : (unsigned)(by_work > 0 ? by_work : 1ull);
         dim3 pgrid((n_waves + waves_per_block - 1) / waves_per_block), pblock(DE_V2_BLOCK);
-        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
-        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, c->stream, a, a.fc);
-        if (MODE != 2) hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, c->stream, a);
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, MODE>), pgrid, pblock, 0, stream, a, a.fc);
+        else hipLaunchKernelGGL((render_kernel_v2<false, MODE>), pgrid, pblock, 0, stream, a, a.fc);
+        if (MODE != 2) {
+            hipError_t pe = pre_acc();
+            if (pe != hipSuccess) return pe;
+            hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, stream, a);
+        }
         return hipGetLastError();
     }
+    hipError_t pe = pre_acc();
+    if (pe != hipSuccess) return pe;
     if (march) {
-        if (clamp) hipLaunchKernelGGL((ray_march_kernel<true, MODE>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((ray_march_kernel<false, MODE>), grid, block, 0, c->stream, a);
-    } else if (clamp) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, c->stream, a);
+        if (clamp) hipLaunchKernelGGL((ray_march_kernel<true, MODE>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((ray_march_kernel<false, MODE>), grid, block, 0, stream, a);
+    } else if (clamp) hipLaunchKernelGGL((render_kernel<true, false, MODE>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((render_kernel<false, false, MODE>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 
@@ -351,14 +421,21 @@ int load_rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.h) return DE_OK;
     void* h = nullptr;
-    if (const char* e = getenv("DE_RCCL_PATH")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    bool only_env = false;
+    if (const char* e = getenv("DE_RCCL_PATH")) {
+        h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        only_env = getenv("DE_RCCL_STRICT") != nullptr;   // test hook: no search beyond DE_RCCL_PATH
+    }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (int pass = 0; pass < 2 && !h; ++pass)
+    for (int pass = 0; pass < 2 && !h && !only_env; ++pass)
         for (const char* n : names) {
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (h) break;
         }
-    if (!h) return fail(DE_ERR_STATE, std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"));
+    if (!h) {
+        const char* why = dlerror();      // ONE call: dlerror() clears the message it returns
+        return fail(DE_ERR_STATE, std::string("cannot load librccl.so: ") + (why ? why : "not found"));
+    }
     Rccl r; r.h = h;
     r.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(void**, int, UniqueId128, int))dlsym(h, "ncclCommInitRank");
@@ -410,8 +487,18 @@ int de_create(int device, int width, int height, de_ctx** out) {
     size_t npx = (size_t)width * height;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     c->own_stream = (e == hipSuccess);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    {   // launches in flight per context (DE_SLOTS, 1..DE_MAX_SLOTS; 1 = every launch waits for the previous one)
+        if (const char* sv = getenv("DE_SLOTS")) { int x = atoi(sv); if (x >= 1 && x <= DE_MAX_SLOTS) c->n_slots = x; }
+        if (const char* sv = getenv("DE_BIG_SLOTS")) { int x = atoi(sv); if (x >= 1 && x <= DE_MAX_SLOTS) c->big_slots = x; }
+        for (int i = 0; i < c->n_slots && e == hipSuccess; ++i) {
+            LaunchSlot& s = c->slot[i];
+            e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreate(&s.t0);
+            if (e == hipSuccess) e = hipEventCreate(&s.t1);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc(&c->d_hdr_own, npx * 3 * sizeof(float));
     c->d_hdr = c->d_hdr_own;
     if (e == hipSuccess) e = hipMalloc(&c->d_image, npx * 3 * sizeof(float));
@@ -420,7 +507,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_nodes, DE_N_NODES * sizeof(LambdaNode));
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, DE_N_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * (DE_MAX_SLOTS + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_dens_table, (size_t)DE_DENS_TABLE_N * 3 * sizeof(float));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
@@ -443,16 +530,26 @@ int de_create(int device, int width, int height, de_ctx** out) {
 
 int de_destroy(de_ctx* c) {
     if (!c) return DE_OK;
+    if (c->loans > 0) return fail(DE_ERR_STATE, "this context lends its maps to another one (de_share_textures): destroy the borrowers first");
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int i = 0; i < DE_MAX_SLOTS; ++i) if (c->slot[i].stream) hipStreamSynchronize(c->slot[i].stream);
+    hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    release_loan(c);
     for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_contrib, c->d_dens_table};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (int i = 0; i < DE_MAX_SLOTS; ++i) {
+        LaunchSlot& s = c->slot[i];
+        if (s.contrib) hipFree(s.contrib);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.t0) hipEventDestroy(s.t0);
+        if (s.t1) hipEventDestroy(s.t1);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return DE_OK;
@@ -489,19 +586,23 @@ int de_generate_texture(de_ctx* c, int slot, int w, int h, uint32_t seed, int va
 int de_share_textures(de_ctx* dst, de_ctx* src) {
     if (!dst || !src || dst == src) return fail(DE_ERR_INVALID, "two different contexts are needed");
     if (dst->device != src->device) return fail(DE_ERR_INVALID, "contexts on different devices cannot share maps");
+    if (src->lender) return fail(DE_ERR_STATE, "the lending context borrows its maps itself: share from their owner");
+    if (dst->loans > 0) return fail(DE_ERR_STATE, "the borrowing context lends its own maps to another one");
     for (int i = 0; i < DE_TEX_COUNT; ++i)
         if (!src->tex[i].set) return fail(DE_ERR_STATE, "the lending context must hold all 7 maps");
     if (!src->luts_set) return fail(DE_ERR_STATE, "the lending context must hold the LUTs");
     HIP_TRY(hipSetDevice(src->device));
-    // bring the lender's packed copies up to date for ITS address mode, then wait: the borrower reads them from another stream
+    // bring the lender's packed copies up to date for ITS address mode, then wait: the borrower reads them from other streams
     const bool clamp = (src->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     for (int i = 0; i < DE_TEX_COUNT; ++i) { int rc = ensure_packed(src, i, clamp); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(src->stream));
-    HIP_TRY(hipStreamSynchronize(dst->stream));
+    { int rc = sync_all(dst); if (rc) return rc; }
+    release_loan(dst);
     for (int i = 0; i < DE_TEX_COUNT; ++i) {
         DevTexture& t = dst->tex[i];
         if (!t.borrowed) { if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
         t = src->tex[i];
+        t.linear = nullptr;       // the as-uploaded copy stays the lender's alone: de_download_texture on the borrower fails cleanly
         t.borrowed = true;
     }
     if (!dst->luts_borrowed) {
@@ -511,6 +612,9 @@ int de_share_textures(de_ctx* dst, de_ctx* src) {
     dst->d_cie = src->d_cie; dst->d_srgb2spec = src->d_srgb2spec; dst->d_o3 = src->d_o3; dst->d_crf = src->d_crf;
     dst->n_crf = src->n_crf; dst->luts_set = true; dst->luts_borrowed = true;
     dst->params_dirty = true; dst->nodes_dirty = true;
+    // the loan is on record: while it lasts the lender refuses to free, replace or repack its maps and LUTs, and to be destroyed
+    dst->lender = src; src->loans++;
+    touched_render_inputs(dst);
     return DE_OK;
 }
 
@@ -521,14 +625,14 @@ int de_trim_textures(de_ctx* c) {
     for (int i = 0; i < DE_TEX_COUNT; ++i) {
         DevTexture& t = c->tex[i];
         if (!t.set || t.borrowed || !t.linear) continue;
-        int rc = ensure_packed(c, i, clamp);          // the packed copy must exist before its source goes
+        int rc = ensure_packed(c, i, clamp);          // the packed copy must exist before its source goes (fails if that means repacking lent maps)
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < DE_TEX_COUNT; ++i) {
         DevTexture& t = c->tex[i];
         if (!t.set || t.borrowed || !t.linear) continue;
-        hipFree(t.linear);
+        hipFree(t.linear);            // borrowers never hold this pointer (de_share_textures)
         t.linear = nullptr;
     }
     return DE_OK;
@@ -537,6 +641,7 @@ int de_trim_textures(de_ctx* c) {
 int de_download_texture(de_ctx* c, int slot, uint8_t* out, uint64_t out_bytes) {
     if (!c || slot < 0 || slot >= DE_TEX_COUNT || !out || !c->tex[slot].set) return fail(DE_ERR_INVALID, "texture not set");
     const DevTexture& t = c->tex[slot];
+    if (t.borrowed) return fail(DE_ERR_STATE, "this map is borrowed (de_share_textures): download it from the context that owns it");
     if (!t.linear) return fail(DE_ERR_STATE, "the as-uploaded copy of this map was released (de_trim_textures)");
     size_t n = (size_t)t.w * t.h * t.ch;
     if (out_bytes < n) return fail(DE_ERR_INVALID, "output buffer too small");
@@ -556,7 +661,10 @@ int de_texture_info(de_ctx* c, int slot, int* w, int* h, int* ch) {
 
 int de_upload_luts(de_ctx* c, const float* cie, const uint16_t* srgb2spec_f16, const float* o3, const float* crf, int n_crf) {
     if (!c || !cie || !srgb2spec_f16 || !o3 || !crf || n_crf <= 0) return fail(DE_ERR_INVALID, "bad LUT arguments");
+    if (c->loans > 0) return fail(DE_ERR_STATE, "the LUTs are lent to another context (de_share_textures): destroy the borrowers first");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    touched_render_inputs(c);
     std::vector<float> q(441 * 2 * 3), s(900), r((size_t)1024 * n_crf * 3);
     for (int i = 0; i < 441 * 2 * 3; ++i) q[i] = quantize_f16(cie[i]);
     for (int i = 0; i < 900; ++i) s[i] = half_to_float(srgb2spec_f16[i]);
@@ -565,6 +673,9 @@ int de_upload_luts(de_ctx* c, const float* cie, const uint16_t* srgb2spec_f16, c
             for (int ch = 0; ch < 3; ++ch) r[((size_t)y * 1024 + x) * 3 + ch] = crf[((size_t)x * n_crf + y) * 3 + ch];
     if (c->luts_borrowed) {                  // stop borrowing: own copies again
         c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; c->luts_borrowed = false;
+        {   bool any = false;
+            for (int i = 0; i < DE_TEX_COUNT; ++i) any = any || c->tex[i].borrowed;
+            if (!any) release_loan(c); }
         HIP_TRY(hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_srgb2spec, 900 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_o3, 441 * sizeof(float)));
@@ -596,6 +707,8 @@ int de_get_params(de_ctx* c, de_params* p) {
 int de_reset(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc = join_slots(c); if (rc) return rc; }
+    touched_hdr(c);
     HIP_TRY(hipMemsetAsync(c->d_hdr, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream));
     memset(&c->counters, 0, sizeof(c->counters));
@@ -627,27 +740,81 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
             return fail(DE_ERR_INVALID, "image too large for render_kernel_v2's 32-bit work-item index");
-        const size_t need = (size_t)a.n_tiles * 64u * (size_t)max_spp;
-        if (need > c->contrib_items) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->d_contrib) hipFree(c->d_contrib);
-            c->d_contrib = nullptr; c->contrib_items = 0;
-            HIP_TRY(hipMalloc(&c->d_contrib, need * sizeof(uint2)));
-            c->contrib_items = need;
-        }
     }
-    a.contrib = c->d_contrib;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // What the context stream has done since the last launch and a launch must be ordered after (set-up kernels, map packing,
+    // the tile list: before the render kernel; reset / display / reduce / uploads of the HDR buffer: before accumulate_kernel).
+    if (c->rec_render != c->gen_render || c->rec_hdr != c->gen_hdr) {
+        HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+        c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
+    }
+    bool first = true;
     for (int done = 0; done < spp && a.n_tiles > 0;) {
         const int n = (spp - done < max_spp) ? spp - done : max_spp;
+        // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
+        // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
+        // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
+        // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
+        const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
+        const int n_cycle = (need_bytes > ((size_t)96 << 20)) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots;
+        const int si = c->next_slot % n_cycle;
+        LaunchSlot& s = c->slot[si];
+        if (v2) {
+            const size_t need = (size_t)a.n_tiles * 64u * (size_t)n;
+            if (need > s.contrib_items) {
+                // grow the record buffers of EVERY slot of this launch's cycle now: the first launch of a new size pays for all
+                // the allocations, none falls between later launches (hipFree / hipMalloc stall the streams)
+                for (int j = 0; j < n_cycle; ++j) {
+                    LaunchSlot& sj = c->slot[j];
+                    if (need <= sj.contrib_items) continue;
+                    HIP_TRY(hipStreamSynchronize(sj.stream));      // the slot's previous launch still reads the old buffer
+                    if (sj.contrib) hipFree(sj.contrib);
+                    sj.contrib = nullptr; sj.contrib_items = 0;
+                    HIP_TRY(hipMalloc(&sj.contrib, need * sizeof(uint2)));
+                    sj.contrib_items = need;
+                }
+            }
+        }
+        a.contrib = s.contrib;
+        a.work_counter = c->d_work_counter + 16 * si;
         a.spp_begin = c->current_spp + done; a.spp_count = n;
         a.spp_magic = ((1ull << 40) / (unsigned long long)n) + 1ull;
-        HIP_TRY(c->count ? launch_render<1>(c, a) : launch_render<0>(c, a));
+        if (s.seen_render != c->gen_render) {
+            HIP_TRY(hipStreamWaitEvent(s.stream, c->ev_main, 0));
+            s.seen_render = c->gen_render; s.seen_hdr = c->gen_hdr;
+        }
+        if (first) { HIP_TRY(hipEventRecord(s.t0, s.stream)); c->t0_slot = si; first = false; }
+        const int prev = c->last_slot;
+        auto pre_acc = [&]() -> hipError_t {
+            if (s.seen_hdr != c->gen_hdr) {
+                hipError_t e = hipStreamWaitEvent(s.stream, c->ev_main, 0);
+                if (e != hipSuccess) return e;
+                s.seen_hdr = c->gen_hdr;
+            }
+            // HDR sums keep launch order: this launch's accumulate_kernel after the previous launch's
+            if (prev >= 0 && prev != si) return hipStreamWaitEvent(s.stream, c->slot[prev].done, 0);
+            return hipSuccess;
+        };
+        HIP_TRY(c->count ? launch_render<1>(c, a, s.stream, pre_acc) : launch_render<0>(c, a, s.stream, pre_acc));
+        HIP_TRY(hipEventRecord(s.done, s.stream));
+        s.pending = true;
+        c->last_slot = si;
+        c->next_slot = (si + 1) % n_cycle;
         done += n;
+        if (done >= spp) { HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true; }
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timing_valid = true;
     c->current_spp += spp;
+    return DE_OK;
+}
+
+/* Make the context stream wait (on the device) for every launch issued so far.  Needed only by a host framework that enqueues
+ * its OWN work on the stream it handed to de_set_stream — e.g. a torch.distributed reduce of the bound HDR tensor; the
+ * library's own entry points (fetch, reduce, reset, display ...) do it themselves. */
+int de_flush(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = join_slots(c);
+    if (rc) return rc;
+    touched_hdr(c);          // whatever the host enqueues next on the stream may touch the HDR buffer
     return DE_OK;
 }
 
@@ -657,6 +824,9 @@ int de_render_to_image(de_ctx* c, const float** device_image) {
     HIP_TRY(hipSetDevice(c->device));
     int rc = run_setup(c);
     if (rc) return rc;
+    rc = join_slots(c);
+    if (rc) return rc;
+    touched_hdr(c);              // the next accumulate_kernel must not overwrite what this reads
     DisplayArgs d;
     d.fc = c->d_fc; d.hdr = c->d_hdr; d.image = c->d_image;
     d.crf.data = c->d_crf; d.crf.w = 1024; d.crf.h = c->n_crf;
@@ -678,7 +848,8 @@ int de_fetch_image(de_ctx* c, float* out) {
 int de_fetch_hdr(de_ctx* c, float* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    size_t npx = (size_t)c->W * c->H;
+    { int rc = join_slots(c); if (rc) return rc; }
+    touched_hdr(c);
     hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
     HIP_TRY(hipGetLastError());
     return copy_out(c, out, c->d_scratch);
@@ -692,6 +863,8 @@ int de_upload_hdr(de_ctx* c, const float* hdr, int spp) {
     for (int i = 0; i < c->W; ++i)
         for (int j = 0; j < c->H; ++j)
             for (int ch = 0; ch < 3; ++ch) t[((size_t)j * c->W + i) * 3 + ch] = hdr[((size_t)i * c->H + j) * 3 + ch];
+    { int rc = join_slots(c); if (rc) return rc; }
+    touched_hdr(c);
     HIP_TRY(hipMemcpyAsync(c->d_hdr, t.data(), npx * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->current_spp = spp;
@@ -709,7 +882,8 @@ int de_hdr_device_ptr(de_ctx* c, void** ptr, uint64_t* n_floats) {
 int de_bind_hdr(de_ctx* c, void* device_ptr, uint64_t n_floats) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { int rc = sync_all(c); if (rc) return rc; }
+    touched_hdr(c);
     if (!device_ptr) { c->d_hdr = c->d_hdr_own; return DE_OK; }
     if (n_floats < (uint64_t)c->W * c->H * 3) return fail(DE_ERR_INVALID, "bound HDR buffer is smaller than W*H*3 floats");
     c->d_hdr = (float*)device_ptr;
@@ -718,29 +892,37 @@ int de_bind_hdr(de_ctx* c, void* device_ptr, uint64_t n_floats) {
 int de_set_stream(de_ctx* c, void* hip_stream) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { int rc = sync_all(c); if (rc) return rc; }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-    c->stream = nullptr; c->own_stream = false;
-    if (!hip_stream) {                       // NULL: back to a stream of the context's own
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-        return DE_OK;
-    }
-    c->stream = (hipStream_t)hip_stream;
+    // NULL is HIP's null stream, as everywhere in HIP (a framework whose current stream IS the null stream — torch's default
+    // stream — passes 0 here and must get exactly that stream, or its own work would not be ordered with the context's)
+    c->stream = (hipStream_t)hip_stream; c->own_stream = false;
+    touched_render_inputs(c); touched_hdr(c);      // whatever the new stream holds, the next launch is ordered after it
+    return DE_OK;
+}
+int de_use_own_stream(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    if (c->own_stream) return DE_OK;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    c->stream = s; c->own_stream = true;
+    touched_render_inputs(c); touched_hdr(c);
     return DE_OK;
 }
 int de_synchronize(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return DE_OK;
+    return sync_all(c);
 }
 int de_last_accumulate_ms(de_ctx* c, float* ms) {
     if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
     if (!c->timing_valid) return fail(DE_ERR_STATE, "no de_accumulate has been issued");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    // from the start of the call's first launch (after its waits) to the end of its last accumulate_kernel
+    HIP_TRY(hipEventSynchronize(c->slot[c->t1_slot].t1));
+    HIP_TRY(hipEventElapsedTime(ms, c->slot[c->t0_slot].t0, c->slot[c->t1_slot].t1));
     return DE_OK;
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
@@ -753,6 +935,7 @@ int de_get_counters(de_ctx* c, de_counters* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[16];
+    { int rc = join_slots(c); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof(*out));
@@ -788,7 +971,7 @@ int de_comm_destroy(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     if (!c->comm) return DE_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { int rc2 = sync_all(c); if (rc2) return rc2; }
     RCCL_TRY(g_rccl.CommDestroy(c->comm));
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     return DE_OK;
@@ -801,6 +984,9 @@ int de_reduce(de_ctx* c, void* comm, int root) {
     int rc = load_rccl();
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    rc = join_slots(c);
+    if (rc) return rc;
+    touched_hdr(c);
     const size_t count = (size_t)c->W * c->H * 3;
     // in place: every rank's buffer is its own tiles plus zeros elsewhere; the root ends with the assembled frame
     RCCL_TRY(g_rccl.Reduce(c->d_hdr, c->d_hdr, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, use, c->stream));
@@ -811,6 +997,7 @@ int de_debug_sched_stats(de_ctx* c, uint64_t* out, int n) {
     if (!c || !out || n < 0 || n > DE_N_COUNTERS - 16) return fail(DE_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     unsigned long long h[DE_N_COUNTERS];
+    { int rc = join_slots(c); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) out[i] = h[16 + i];
@@ -829,7 +1016,10 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     a.spp_begin = sample_index; a.spp_count = 1;
     a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
-    HIP_TRY(launch_render<2>(c, a));
+    a.work_counter = c->d_work_counter + 16 * DE_MAX_SLOTS;     // a counter of its own: launches in the slots keep theirs
+    rc = join_slots(c);
+    if (rc) return rc;
+    HIP_TRY(launch_render<2>(c, a, c->stream, []() -> hipError_t { return hipSuccess; }));
     HIP_TRY(hipMemcpyAsync(out, c->d_scratch, (size_t)c->W * c->H * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return DE_OK;

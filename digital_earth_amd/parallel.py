@@ -88,6 +88,8 @@ class DistributedFrame:
         with self.torch.cuda.stream(self.stream):
             self.r.reset_framebuffer()        # zeroes the bound HDR buffer on the frame's stream
             self.r.accumulate(spp)
+            if self.world > 1:
+                self.r.flush()                # the collective below is torch's own work on this stream: order it after the launches
             reduce_hdr(self.hdr, dst=0)
             if self.rank == 0:
                 self.r.render_to_image_device()

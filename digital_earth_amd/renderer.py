@@ -113,9 +113,11 @@ class Renderer:
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
+        """de_destroy.  Fails (DigitalEarthError, DE_ERR_STATE) while another Renderer still borrows this one's maps."""
         if getattr(self, "_h", None):
-            self._lib.de_destroy(self._h)
+            check(self._lib.de_destroy(self._h))
             self._h = ctypes.c_void_p()
+            self._lender = None
 
     def __del__(self):
         try:
@@ -231,6 +233,9 @@ class Renderer:
         check(self._lib.de_trim_textures(self._h))
 
     def download_texture(self, slot):
+        """The map as uploaded.  A borrower (share_textures_from) holds no as-uploaded copy: the owner's is returned."""
+        if getattr(self, "_lender", None) is not None:
+            return self._lender.download_texture(slot)
         w, h, ch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.de_texture_info(self._h, slot, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)))
         out = np.zeros((h.value, w.value, ch.value), dtype=np.uint8)
@@ -393,7 +398,7 @@ class Renderer:
     def unbind(self):
         """Back to the library's own HDR buffer and stream (undoes bind_hdr / set_stream)."""
         check(self._lib.de_bind_hdr(self._h, None, 0))
-        check(self._lib.de_set_stream(self._h, None))
+        check(self._lib.de_use_own_stream(self._h))
         self._bound = None
 
     # in-library collective (include/digital_earth.h: de_comm_*, de_reduce)
@@ -423,7 +428,13 @@ class Renderer:
         return p.value
 
     def set_stream(self, hip_stream_handle):
-        check(self._lib.de_set_stream(self._h, ctypes.c_void_p(hip_stream_handle)))
+        """Use the caller's HIP stream as the context stream; 0 / None is HIP's null stream (torch's default stream)."""
+        check(self._lib.de_set_stream(self._h, ctypes.c_void_p(hip_stream_handle or None)))
+
+    def flush(self):
+        """Make the context stream wait (on the device) for every accumulate() issued so far — before the caller enqueues
+        work of its own on that stream (parallel.reduce_hdr on the bound tensor)."""
+        check(self._lib.de_flush(self._h))
 
     def upload_hdr(self, hdr, spp):
         """Load an accumulation state ((W, H, 3) float32 sums, sample count) — resume of a progressive render."""

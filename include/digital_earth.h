@@ -7,8 +7,11 @@
  *
  * Conventions: every function returns 0 on success or a negative DE_ERR_* code and never throws;
  * de_last_error() returns a thread-local message for the last failure.  The caller owns every host
- * pointer; the library owns all device memory.  One context = one GPU = one HIP stream; calls on one
- * context are not thread-safe (the reference is single-threaded, earth_viewer.py:183-318).
+ * pointer; the library owns all device memory.  One context = one GPU; calls on one context are not thread-safe
+ * (the reference is single-threaded, earth_viewer.py:183-318).  A context has ONE stream visible to the caller (the
+ * "context stream": reset, display, fetch, reduce, uploads) and a few internal launch slots with streams of their own on
+ * which de_accumulate runs, so that consecutive de_accumulate calls overlap (see de_accumulate); every entry point orders
+ * itself against them, a caller only needs de_flush when it enqueues its OWN work on a stream given to de_set_stream.
  * There is no CPU fallback: de_create fails with DE_ERR_NO_DEVICE when no gfx950 device is usable.
  */
 #ifndef DIGITAL_EARTH_H
@@ -20,7 +23,12 @@
 extern "C" {
 #endif
 
-#define DE_ABI_VERSION 1
+/* 1: round 1.  2: round 2 (contract-2 arithmetic, de_share_textures / de_trim_textures / de_comm_* added, DE_FLAG_NO_FAST_DIVISION
+ * retired) — shipped still reporting 1.  3: launch slots (de_flush), de_use_own_stream, de_set_stream(NULL) = the null stream,
+ * loans recorded by de_share_textures. */
+#define DE_ABI_VERSION 3
+/* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
+#define DE_ARITHMETIC_CONTRACT 2
 
 enum {
     DE_OK = 0,
@@ -99,9 +107,11 @@ int de_upload_texture(de_ctx* ctx, int slot, const uint8_t* texels, int width, i
 /* Synthetic stand-in for the NASA maps that the reference does not ship: generated on the GPU,
  * deterministic in (slot, width, height, seed, variant).  variant 1 = cloud-heavy (BASELINE cfg4). */
 int de_generate_texture(de_ctx* ctx, int slot, int width, int height, uint32_t seed, int variant);
-/* Let `dst` use the maps and LUTs that `src` holds on the same device instead of copies of its own (a second frame in
- * flight, a second view of the same Earth: 9 GB at quality 2).  Read-only borrowing: `src` must outlive `dst` or `dst`
- * must upload / generate maps of its own before `src` is destroyed; the borrowed maps keep `src`'s address mode. */
+/* Let `dst` use the maps and LUTs that `src` holds on the same device instead of copies of its own (a second view of the
+ * same Earth: 9 GB at quality 2).  Read-only borrowing; the borrowed maps keep `src`'s address mode.  The loan is recorded on
+ * `src`: until every borrower has been destroyed or holds maps and LUTs of its own again, de_destroy, de_upload_texture,
+ * de_generate_texture, de_upload_luts and a change of the sampler address mode on `src` fail with DE_ERR_STATE (nothing a
+ * borrower reads can be freed or repacked under it).  de_download_texture on a borrower fails with DE_ERR_STATE. */
 int de_share_textures(de_ctx* dst, de_ctx* src);
 /* Release the as-uploaded (linear u8) copies of the maps, 2.1 GB at quality 2, keeping the packed copies the kernels read.
  * Afterwards de_download_texture and a change of the sampler address mode fail with DE_ERR_STATE until the maps are
@@ -127,7 +137,10 @@ int de_reset(de_ctx* ctx);
 /* accumulate (renderer.py:371-380) `spp` times: adds samples current_spp .. current_spp+spp-1 of every pixel
  * owned by (tile_rank, tile_world) to color_buffer, then current_spp += spp.  The RNG stream of a sample is a
  * function of (seed, absolute pixel index, sample index) only, so images do not depend on tile_world.
- * Ownership: 8x8-pixel tile (tx, ty) belongs to rank (tx + ty) % tile_world.  Asynchronous on the context stream. */
+ * Ownership: 8x8-pixel tile (tx, ty) belongs to rank (tx + ty) % tile_world.
+ * Asynchronous.  Consecutive calls go to internal launch slots in turn (8; 3 for launches with more than 96 MB of per-sample records; env DE_SLOTS / DE_BIG_SLOTS = 1..8) and overlap on
+ * the GPU: k calls of 1 spp — the reference's interactive pattern, earth_viewer.py:241-243 — cost about what one call of
+ * k spp costs.  The additions to color_buffer stay in call order (same bits as serial execution). */
 int de_accumulate(de_ctx* ctx, int spp, uint64_t seed, int tile_rank, int tile_world);
 
 /* fetch_image (renderer.py:382-384, 346-365): runs _render_to_image with samples = current_spp and copies
@@ -150,8 +163,13 @@ int de_hdr_device_ptr(de_ctx* ctx, void** ptr, uint64_t* n_floats);
 /* Use caller-owned device memory (n_floats >= W*H*3, e.g. a torch tensor's data_ptr) as the HDR buffer; the current
  * contents are kept as the accumulation state.  ptr = NULL returns to the library's own buffer. */
 int de_bind_hdr(de_ctx* ctx, void* device_ptr, uint64_t n_floats);
-/* hip_stream = NULL: back to a stream owned by the context. */
+/* Use the caller's hipStream_t as the context stream.  NULL is HIP's null stream (what a framework whose current stream is the
+ * default stream passes), NOT "the context's own stream": that is de_use_own_stream. */
 int de_set_stream(de_ctx* ctx, void* hip_stream);
+int de_use_own_stream(de_ctx* ctx);
+/* Make the context stream wait, on the device, for every de_accumulate issued so far (returns at once).  For hosts that enqueue
+ * their own work on a stream given to de_set_stream — e.g. a torch.distributed reduce of the tensor bound with de_bind_hdr. */
+int de_flush(de_ctx* ctx);
 
 /* The collective of the tile partition inside the library (SURVEY §8b `de_reduce`, §8e): one in-place
  * ncclReduce(sum, f32, count = W*H*3) of the HDR buffer to `root` over RCCL / xGMI, enqueued on the context's stream
@@ -166,7 +184,8 @@ int de_comm_destroy(de_ctx* ctx);
 int de_reduce(de_ctx* ctx, void* comm, int root);
 int de_synchronize(de_ctx* ctx);
 
-/* Timing of the last de_accumulate on the context's own stream, measured with HIP events (ms). */
+/* Duration of the last de_accumulate call measured with HIP events on its launch slot (ms): from the start of its first
+ * render launch to the end of its last accumulate_kernel. */
 int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);

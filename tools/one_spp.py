@@ -1,11 +1,47 @@
-import sys, time; sys.path.insert(0,'.')
+#!/usr/bin/env python3
+"""Small launches: k x accumulate(1) against accumulate(k) (the reference's interactive loop is accumulate() x 1
+per frame, earth_viewer.py:241-243).  Run with DE_SLOTS=1 for the serial behaviour of round 2.
+
+  python tools/one_spp.py [--check]      --check: the HDR sums of the k x 1 render equal those of the 1 x k render bit for bit
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
 from digital_earth_amd.renderer import Renderer
-r = Renderer((1920,1080),(0,1,0),texture_source="synthetic"); r.copy_textures()
-for spp in (1, 4, 16):
-    r.reset_framebuffer(); r.accumulate(spp); r.synchronize()
-    t0=time.perf_counter(); n=64//spp
-    for i in range(n): r.accumulate(spp)
-    r.synchronize(); t1=time.perf_counter()
-    print("spp per launch %2d: %d launches, %.1f ms total, %.2f ms per launch, %.0f Msamples/s" % (spp, n, (t1-t0)*1e3, (t1-t0)*1e3/n, 1920*1080*64/(t1-t0)/1e6))
-t0=time.perf_counter(); r.reset_framebuffer(); r.accumulate(1); img=r.fetch_image(); t1=time.perf_counter()
-print("reset + accumulate(1) + fetch_image (host copy): %.2f ms" % ((t1-t0)*1e3))
+
+W, H = 1920, 1080
+r = Renderer((W, H), (0, 1, 0), texture_source="synthetic")
+r.copy_textures()
+r.reset_framebuffer(); r.accumulate(16); r.synchronize()           # allocations, first-launch costs
+
+
+def timed(spp, n):
+    r.reset_framebuffer(); r.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r.accumulate(spp)
+    r.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+print("launch slots: DE_SLOTS=%s" % os.environ.get("DE_SLOTS", "default"))
+base = {}
+for total in (16, 64):
+    base[total] = min(timed(total, 1) for _ in range(3))
+    print("accumulate(%d) x 1: %.1f ms = %.0f Msamples/s" % (total, base[total], W * H * total / base[total] / 1e3))
+for spp, total in ((1, 16), (4, 16), (1, 64), (4, 64), (16, 64)):
+    n = total // spp
+    ms = min(timed(spp, n) for _ in range(3))
+    print("accumulate(%d) x %d: %.1f ms = %.0f Msamples/s, %.2fx the time of accumulate(%d)" % (spp, n, ms, W * H * total / ms / 1e3, ms / base[total], total))
+t0 = time.perf_counter(); r.reset_framebuffer(); r.accumulate(1); img = r.fetch_image(); t1 = time.perf_counter()
+print("reset + accumulate(1) + fetch_image (host copy): %.2f ms" % ((t1 - t0) * 1e3))
+if "--check" in sys.argv:
+    r.reset_framebuffer(); r.accumulate(16); a = r.fetch_hdr()
+    r.reset_framebuffer()
+    for _ in range(16):
+        r.accumulate(1)
+    b = r.fetch_hdr()
+    print("16 x accumulate(1) vs accumulate(16): bit-identical fraction %.6f" % float((a.view(np.uint32) == b.view(np.uint32)).mean()))

@@ -19,6 +19,11 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
         out.append("| %s | %s | %.3f | %.3f | %s |" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                       float(r["AverageNs"]) / 1e6, r.get("Percentage", "")))
     out.append("")
+    # average duration of the dominant kernel (the 64-spp launches of the production mode), for bench.py's staleness check
+    kernel_ms = None
+    for r in stats:
+        if r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
+            kernel_ms = float(r["AverageNs"]) / 1e6
     pmc = defaultdict(list)
     for d in glob.glob(os.path.join(root, "pmc_*")):
         for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")):
@@ -49,7 +54,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                 miss = means.get("TCC_MISS_sum")
                 json.dump({"workload": workload, "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + wr_kb * 1024,
                            "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
-                           "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag,
+                           "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag, "kernel_ms": kernel_ms,
                            "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"]) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None),
                            "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), per 64-spp launch; read bytes = 2 x FETCH_SIZE "
                                    "(a request moves a 128-B line and is tallied as 64 B — calibrated for scattered dword loads in "
