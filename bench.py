@@ -365,7 +365,7 @@ def main():
         c = o.fetch_hdr().astype(np.float64)
         out["parity"] = {"rel_l2_vs_cpu_port": float(np.sqrt(((g - c) ** 2).sum()) / max(np.sqrt((c ** 2).sum()), 1e-300)),
                          "bit_identical_fraction": float((g == c).mean()), "spp": args.cpu_spp,
-                         "note": "vs oracle/ (the build's CPU restatement; parity with the Taichi reference itself is unpinned, DESIGN §2)"}
+                         "note": "vs oracle/ (the build's CPU restatement, itself held to the reference's executed text by tests/test_ref_fixtures.py; Taichi-internal arithmetic is defined, not pinned: DESIGN §2)"}
         out["speedup_vs_cpu_port"] = value / base["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -157,8 +157,8 @@ DE_DEV vec3 openDR_transform(const FrameConsts& k, float p_R, float p_G, float p
     rgb = rats * ts;
     return v3(de_min(rgb.x, k.drt_clamp_max), de_min(rgb.y, k.drt_clamp_max), de_min(rgb.z, k.drt_clamp_max));
 }
-// lib/AgX.py:87-159 (the alternative display transform kept behind a comment at renderer.py:356); display_transform has
-// no `return` in the reference: its final `workingColor` is the value.
+// lib/AgX.py:87-159 (the alternative display transform kept behind a comment at renderer.py:356); display_transform ends
+// with `return clamp(workingColor, 0., 1.)` (:159).
 DE_DEV float agx_hyperbolic(float x, float power) { return x / de_pow(1.0f + de_pow(x, power), 1.0f / power); }   // :103-105
 DE_DEV float agx_full_curve(const FrameConsts& k, float x) {                                                       // :111-127
     const bool upper = x >= k.agx_x_pivot;
@@ -182,7 +182,8 @@ DE_DEV vec3 agx_display_transform(const FrameConsts& k, vec3 c) {               
         o[i] = de_clamp(agx_full_curve(k, x), 0.0f, 1.0f);
     }
     vec3 w = v3(o[0], o[1], o[2]);
-    return mix3(lum3(w), w, (float)1.4);
+    w = mix3(lum3(w), w, (float)1.4);
+    return v3(de_clamp(w.x, 0.0f, 1.0f), de_clamp(w.y, 0.0f, 1.0f), de_clamp(w.z, 0.0f, 1.0f));   // :159 `return clamp(workingColor, 0., 1.)`
 }
 }  // namespace
 

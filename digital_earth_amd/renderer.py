@@ -255,7 +255,9 @@ class Renderer:
 
     def set_up(self, x, y, z):
         v = np.array([x, y, z], dtype=np.float32)
-        v = v / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])      # ti.Vector.normalized() in f32
+        # ti.Vector.normalized() in f32 (taichi/lang/matrix.py): invlen = 1 / norm; invlen * v — checked against the value the
+        # reference's set_up kernel stores (tests/golden/ref_frames_*.npz, tests/test_gpu_ref_fixtures.py)
+        v = (np.float32(1.0) / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])) * v
         self._params.up[0], self._params.up[1], self._params.up[2] = float(v[0]), float(v[1]), float(v[2])
         self._push_params()
 

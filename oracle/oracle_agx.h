@@ -1,9 +1,9 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
 // oracle_agx.h — restatement of lib/AgX.py:1-159 (Troy Sobotka's AgX as a shader, the alternative display transform
 // the reference keeps behind a comment at renderer.py:356: `output = srgb_transfer(agx.display_transform(linear))`).
-// lib/AgX.py:130-159 `display_transform` ends without a `return`; the value restated here is its final
-// `workingColor`.  Matrix set-up (PrimariesToMatrix, ComputeCompressionMatrix, InverseMat, :22-85) and the two
+// lib/AgX.py:130-159 `display_transform` returns clamp(workingColor, 0, 1) (its last line, :159 — rounds 1 and 2 had missed it
+// and returned the un-clamped saturation mix; found in round 3 by executing the reference's text, tests/golden/ref_leaves.npz).  Matrix set-up (PrimariesToMatrix, ComputeCompressionMatrix, InverseMat, :22-85) and the two
 // AgXScale constants (:99-101) depend on module constants only: evaluated in double, rounded to f32 once.
 #pragma once
 #include "oracle_lib.h"
@@ -84,7 +84,8 @@ static inline vec3 display_transform(vec3 c) {
         o[i] = clamp_(full_curve(k, x), 0.0f, 1.0f);
     }
     vec3 w(o[0], o[1], o[2]);
-    return mix(lum3(w), w, (float)SATURATION);
+    w = mix(lum3(w), w, (float)SATURATION);
+    return vec3(clamp_(w.x, 0.0f, 1.0f), clamp_(w.y, 0.0f, 1.0f), clamp_(w.z, 0.0f, 1.0f));   // :159 `return clamp(workingColor, 0., 1.)`
 }
 
 }  // namespace agx

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED: the reference has no
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). the reference has no
 // tests or golden vectors for this path and cannot be executed here (needs Taichi + Vulkan).
 //
 // oracle_lib.h — CPU restatement of the reference's leaf libraries, one function per reference

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
 // oracle_opendrt.h — restatement of lib/OpenDRT.py:77-131,191-218,221-485 (OpenDRT v0.2.2, GPLv3 upstream)
 // for the configuration the reference actually runs (lib/OpenDRT.py:39-55): in_gamut = Rec709,

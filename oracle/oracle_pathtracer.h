@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
 //
 // oracle_pathtracer.h — restatement of /root/reference/pathtracer.py:11-469 (path_tracer, live) and
 // :471-685 (ray_marcher, dead in the reference but named by BASELINE.json's north_star).
