@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--tex-size", type=int, nargs=2, default=None, help="override the size of every synthetic map (tests)")
     ap.add_argument("--reduce", choices=("torch", "lib"), default=os.environ.get("DE_REDUCE", "torch"),
                     help="N > 1 collective: torch.distributed (default) or the library's own RCCL communicator (de_comm_init / de_reduce)")
+    ap.add_argument("--progressive", type=int, default=0, metavar="K",
+                    help="progressive frames (BASELINE cfg5, SURVEY §8e): out-of-place reduce + display every K spp instead of once per frame")
+    ap.add_argument("--waves-per-cu", type=int, default=0,
+                    help="resident render waves per CU (1..20, default 20 = 5 per SIMD)")
+    ap.add_argument("--serial-frames", action="store_true",
+                    help="one launch at a time (launch slots = 1): the collective of frame k never waits behind frame k+1's persistent waves")
     ap.add_argument("--dump-hdr", default=None, help="rank 0: save the assembled HDR frame of the LAST step as .npy (tests)")
     ap.add_argument("--check-spp", type=int, default=2, help="N > 1: spp of the untimed parity check of the assembled frame against a 1-rank render on rank 0 (0 = skip)")
     return ap.parse_args()
@@ -185,10 +191,25 @@ def main():
                 return box[0]
             frames.append(parallel.LibraryComm(rk, rank, world, exchange))
         else:
-            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index)))
+            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index, priority=-1)))
         if args.simulate_world > 1 and world == 1:
             rk.set_tile_partition(0, args.simulate_world)
     r, frame = frames[0].r, frames[0]
+    # Launch settings.  Frames overlap through the library's launch slots (3 for frame-sized launches).  With N > 1 the collective
+    # of frame k is then enqueued while frame k+1 renders: the render kernel's persistent waves own every vector register of the
+    # CUs (5 per SIMD x 96 VGPRs), so the collective's kernel gets CUs as those waves drain (the frame's tail) — its stream has
+    # the highest priority, so that freed wave slots go to it before the next frame's workgroups.  (Capping the waves per launch
+    # does not leave room for it: 16 per CU cost 2 % on one GPU but the next launch in flight takes the free slots.)  Throughput
+    # holds either way — the render launches do not wait for the collective — but the latency of a frame grows; `alt` below
+    # times the same steps with one launch at a time, where the collective never queues behind a render.
+    def apply_settings(serial, wpc):
+        for f in frames:
+            f.r.synchronize()
+            f.r.set_launch_slots(1 if serial else 8, 1 if serial else 3)
+            f.r.set_wave_budget(wpc)
+    serial = bool(args.serial_frames)
+    wpc = args.waves_per_cu if args.waves_per_cu > 0 else 20
+    apply_settings(serial, wpc)
     # the CPU-baseline leg (after the timed region) needs the maps as uploaded: take them to the host now, then release the
     # 2.1 GB of as-uploaded device copies — the kernels read the packed copies only
     maps = None
@@ -215,24 +236,33 @@ def main():
 
     # every context in flight allocates its per-sample buffer at its first full-size launch: prime them all (untimed), whatever
     # --warmup says, so that no allocation can fall into the timed region
+    def step(f):
+        if args.progressive > 0:
+            f.render_frame_progressive(spp, args.progressive)
+        else:
+            f.render_frame(spp)
+
+    def timed(n_steps):
+        barrier()
+        ta = time.perf_counter()
+        for i in range(n_steps):
+            step(frames[i % len(frames)])
+        barrier()
+        return time.perf_counter() - ta
+
     for f in frames:
-        f.render_frame(spp)
+        for _ in range(3):                 # every launch slot of every context allocates its record buffer at its first launch
+            step(f)
     barrier()
     for i in range(args.warmup):
-        frames[i % len(frames)].render_frame(spp)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        frames[i % len(frames)].render_frame(spp)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+        step(frames[i % len(frames)])
+    elapsed = timed(args.steps)
     last = frames[(args.steps - 1) % len(frames)]
     if args.dump_hdr and rank == 0:
         np.save(args.dump_hdr, last.r.fetch_hdr())
 
     # untimed: one frame at a time (latency of a single frame), with the HIP-event duration of its render launch
-    per_launch, per_frame = [], []
+    per_launch, per_frame, per_reduce = [], [], []
     for _ in range(max(1, min(args.steps, 3))):
         barrier()
         tf = time.perf_counter()
@@ -240,15 +270,33 @@ def main():
         barrier()
         per_frame.append(time.perf_counter() - tf)
         per_launch.append(r.last_accumulate_ms())
+        per_reduce.append(frame.last_reduce_ms() if world > 1 else 0.0)
     avg_kernel_ms = float(np.mean(per_launch))
     single_frame_ms = float(np.mean(per_frame)) * 1e3
+    my_render_ms, my_reduce_ms = avg_kernel_ms, float(np.mean(per_reduce))
+
+    # N > 1: the same K steps under the OTHER launch setting (serial <-> overlapping), untimed by the contract, reported as `alt`
+    alt = None
+    if world > 1:
+        alt_serial = not serial
+        alt_wpc = wpc
+        apply_settings(alt_serial, alt_wpc)
+        for _ in range(2):
+            step(frame)
+        alt_elapsed = timed(args.steps)
+        alt = {"serial_frames": alt_serial, "waves_per_cu": alt_wpc, "elapsed_s": alt_elapsed}
+        apply_settings(serial, wpc)
 
     multi = None
     if world > 1:
         dev_t = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed, avg_kernel_ms, single_frame_ms], dtype=torch.float64, device=dev_t)
+        t = torch.tensor([elapsed, avg_kernel_ms, single_frame_ms, alt["elapsed_s"]], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, avg_kernel_ms, single_frame_ms = (float(x) for x in t.tolist())
+        elapsed, avg_kernel_ms, single_frame_ms, alt["elapsed_s"] = (float(x) for x in t.tolist())
+        # what every rank measured on its own (HIP events): render launch, collective; and the tiles it owns
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "render_ms": my_render_ms, "reduce_ms": my_reduce_ms,
+                                          "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank])})
         if args.check_spp > 0:
             # parity of the N-rank path on THIS hardware: the assembled frame must equal a 1-rank render bit for bit.
             # Untimed and after the measurement; a failure here is reported in the line, it does not lose the measurement.
@@ -257,18 +305,17 @@ def main():
                 barrier()
                 if rank == 0:
                     assembled = frame.r.fetch_hdr()
-                    solo = frames[-1].r if len(frames) > 1 else None
-                    if solo is not None:
-                        solo.synchronize()
-                        keep = (solo.tile_rank, solo.tile_world)
-                        solo.set_tile_partition(0, 1)
-                        solo.reset_framebuffer()
-                        solo.accumulate(args.check_spp)
-                        solo_hdr = solo.fetch_hdr()
-                        solo.set_tile_partition(*keep)
-                        multi = {"spp": args.check_spp,
-                                 "bit_identical_fraction": float((assembled.view(np.uint32) == solo_hdr.view(np.uint32)).mean()),
-                                 "nonzero_pixels": int((assembled != 0).any(axis=2).sum())}
+                    solo = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)     # a 1-rank render of the same frame
+                    if args.preset:
+                        apply_preset(solo, args.preset)
+                    solo.set_integrator(args.integrator)
+                    solo.share_textures_from(r)
+                    solo.accumulate(args.check_spp)
+                    solo_hdr = solo.fetch_hdr()
+                    solo.close()
+                    multi = {"spp": args.check_spp,
+                             "bit_identical_fraction": float((assembled.view(np.uint32) == solo_hdr.view(np.uint32)).mean()),
+                             "nonzero_pixels": int((assembled != 0).any(axis=2).sum())}
                 barrier()
             except Exception as exc:          # noqa: BLE001 - reported, not swallowed
                 multi = {"spp": args.check_spp, "error": "%s: %s" % (type(exc).__name__, exc)}
@@ -322,7 +369,8 @@ def main():
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
                    "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
-                   "frames_in_flight": len(frames),
+                   "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3, "waves_per_cu": wpc,
+                   "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
@@ -336,6 +384,11 @@ def main():
     }
     if multi is not None:
         out["multi_gpu_parity"] = multi
+    if world > 1:
+        out["per_rank"] = per_rank
+        alt["value"] = total_samples / alt["elapsed_s"] / 1e6
+        alt["ms_per_step"] = alt["elapsed_s"] / args.steps * 1e3
+        out["alt"] = alt
     if valu_insts:
         # The bound that holds is VALU issue.  Instructions per launch = SQ_INSTS_VALU of the committed rocprofv3 --pmc pass
         # of this workload (profiles/); active lanes per instruction = its SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU).

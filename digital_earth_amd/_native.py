@@ -71,6 +71,11 @@ SYMBOLS = {
     "de_comm_init": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
     "de_comm_destroy": (ctypes.c_int, [_P]),
     "de_reduce": (ctypes.c_int, [_P, _P, ctypes.c_int]),
+    "de_reduce_progressive": (ctypes.c_int, [_P, _P, ctypes.c_int]),
+    "de_last_reduce_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
+    "de_set_display_source": (ctypes.c_int, [_P, _P]),
+    "de_set_launch_slots": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+    "de_set_wave_budget": (ctypes.c_int, [_P, ctypes.c_int]),
     "de_synchronize": (ctypes.c_int, [_P]),
     "de_last_accumulate_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(DeCounters)]),

@@ -196,6 +196,10 @@ struct de_ctx {
     bool count = false;
     de_counters counters;
     int current_spp = 0;
+    float* d_assembled = nullptr;   // root's receive buffer of de_reduce_progressive ([H][W][3])
+    const float* display_src = nullptr;   // what the display transform / de_fetch_hdr read instead of d_hdr (de_set_display_source)
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;   // around the last collective
+    bool reduce_timing_valid = false;
     void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
     int comm_rank = 0, comm_world = 1;
     int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip)
@@ -485,7 +489,11 @@ int de_create(int device, int width, int height, de_ctx** out) {
     }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // the context stream carries the small operations between frames and the collective: highest priority, so that wave slots
+    // freed by the draining render kernels of the launch slots go to them first
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
     c->own_stream = (e == hipSuccess);
     {   // launches in flight per context (DE_SLOTS, 1..DE_MAX_SLOTS; 1 = every launch waits for the previous one)
         if (const char* sv = getenv("DE_SLOTS")) { int x = atoi(sv); if (x >= 1 && x <= DE_MAX_SLOTS) c->n_slots = x; }
@@ -538,7 +546,7 @@ int de_destroy(de_ctx* c) {
     release_loan(c);
     for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
@@ -550,6 +558,8 @@ int de_destroy(de_ctx* c) {
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_r0) hipEventDestroy(c->ev_r0);
+    if (c->ev_r1) hipEventDestroy(c->ev_r1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return DE_OK;
@@ -713,6 +723,7 @@ int de_reset(de_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream));
     memset(&c->counters, 0, sizeof(c->counters));
     c->current_spp = 0;
+    if (c->display_src == c->d_assembled) c->display_src = nullptr;    // the assembled frame of a progressive reduce is history now
     return DE_OK;
 }
 
@@ -828,7 +839,7 @@ int de_render_to_image(de_ctx* c, const float** device_image) {
     if (rc) return rc;
     touched_hdr(c);              // the next accumulate_kernel must not overwrite what this reads
     DisplayArgs d;
-    d.fc = c->d_fc; d.hdr = c->d_hdr; d.image = c->d_image;
+    d.fc = c->d_fc; d.hdr = c->display_src ? c->display_src : c->d_hdr; d.image = c->d_image;
     d.crf.data = c->d_crf; d.crf.w = 1024; d.crf.h = c->n_crf;
     d.W = c->W; d.H = c->H; d.samples = c->current_spp; d.clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) ? 1 : 0;
     size_t npx = (size_t)c->W * c->H;
@@ -850,7 +861,7 @@ int de_fetch_hdr(de_ctx* c, float* out) {
     HIP_TRY(hipSetDevice(c->device));
     { int rc = join_slots(c); if (rc) return rc; }
     touched_hdr(c);
-    hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, c->d_hdr, c->d_scratch, c->W, c->H);
+    hipLaunchKernelGGL(hdr_transpose_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, c->display_src ? c->display_src : c->d_hdr, c->d_scratch, c->W, c->H);
     HIP_TRY(hipGetLastError());
     return copy_out(c, out, c->d_scratch);
 }
@@ -906,7 +917,9 @@ int de_use_own_stream(de_ctx* c) {
     { int rc = sync_all(c); if (rc) return rc; }
     if (c->own_stream) return DE_OK;
     hipStream_t s = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi));
     c->stream = s; c->own_stream = true;
     touched_render_inputs(c); touched_hdr(c);
     return DE_OK;
@@ -976,7 +989,8 @@ int de_comm_destroy(de_ctx* c) {
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     return DE_OK;
 }
-int de_reduce(de_ctx* c, void* comm, int root) {
+namespace {
+int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     void* use = comm ? comm : c->comm;
     if (!use) return fail(DE_ERR_STATE, "no communicator: pass an ncclComm_t or call de_comm_init");
@@ -986,10 +1000,63 @@ int de_reduce(de_ctx* c, void* comm, int root) {
     HIP_TRY(hipSetDevice(c->device));
     rc = join_slots(c);
     if (rc) return rc;
-    touched_hdr(c);
     const size_t count = (size_t)c->W * c->H * 3;
-    // in place: every rank's buffer is its own tiles plus zeros elsewhere; the root ends with the assembled frame
-    RCCL_TRY(g_rccl.Reduce(c->d_hdr, c->d_hdr, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, use, c->stream));
+    float* recv = c->d_hdr;
+    if (progressive) {
+        // out of place: every rank keeps accumulating into its own buffer; the root receives the assembled frame elsewhere
+        if (!c->d_assembled) HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
+        recv = c->d_assembled;
+    } else {
+        touched_hdr(c);
+    }
+    if (!c->ev_r0) { HIP_TRY(hipEventCreate(&c->ev_r0)); HIP_TRY(hipEventCreate(&c->ev_r1)); }
+    HIP_TRY(hipEventRecord(c->ev_r0, c->stream));
+    // every rank's buffer is its own tiles plus zeros elsewhere; the root ends with the assembled frame
+    RCCL_TRY(g_rccl.Reduce(c->d_hdr, recv, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, use, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
+    c->reduce_timing_valid = true;
+    if (progressive) {
+        touched_hdr(c);                        // the collective READS d_hdr: the next accumulate_kernel is ordered after it
+        c->display_src = c->d_assembled;
+    }
+    return DE_OK;
+}
+}  // namespace
+
+int de_reduce(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, false); }
+int de_reduce_progressive(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, true); }
+int de_last_reduce_ms(de_ctx* c, float* ms) {
+    if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
+    if (!c->reduce_timing_valid) return fail(DE_ERR_STATE, "no de_reduce has been issued");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_r1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_r0, c->ev_r1));
+    return DE_OK;
+}
+int de_set_display_source(de_ctx* c, const void* device_ptr) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    c->display_src = (const float*)device_ptr;
+    return DE_OK;
+}
+int de_set_launch_slots(de_ctx* c, int n_slots, int n_big) {
+    if (!c || n_slots < 1 || n_slots > DE_MAX_SLOTS || n_big < 1 || n_big > DE_MAX_SLOTS) return fail(DE_ERR_INVALID, "slot counts must be 1..8");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int i = c->n_slots; i < n_slots; ++i) {          // slots that did not exist yet
+        LaunchSlot& s = c->slot[i];
+        if (s.stream) continue;
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&s.t0));
+        HIP_TRY(hipEventCreate(&s.t1));
+    }
+    c->n_slots = n_slots; c->big_slots = n_big;
+    c->next_slot = 0; c->last_slot = -1;
+    return DE_OK;
+}
+int de_set_wave_budget(de_ctx* c, int waves_per_cu) {
+    if (!c || waves_per_cu < 1 || waves_per_cu > 20) return fail(DE_ERR_INVALID, "waves per CU must be 1..20");
+    c->tune_wpc = waves_per_cu;
     return DE_OK;
 }
 

@@ -36,28 +36,38 @@ def tiles_per_rank(width, height, world):
     return np.bincount(owner.ravel(), minlength=world)
 
 
-def reduce_hdr(hdr, dst=0, group=None):
-    """Sum the per-rank HDR buffers onto rank `dst` (in place).  One collective per fetch, not per sample:
-    24.9 MB at 1080p, 99.5 MB at 4K.
+def reduce_hdr(hdr, dst=0, group=None, out=None):
+    """Sum the per-rank HDR buffers onto rank `dst`.  One collective per fetch, not per sample: 24.9 MB at 1080p, 99.5 MB at 4K.
 
-    RCCL ("nccl") reduces the device tensor in place on the current stream.  gloo has no reduce for device tensors:
-    there the buffer is staged through host memory (the 2-ranks-on-one-GPU dry run and the CPU tests)."""
+    out=None: in place (the root's buffer becomes the assembled frame — the one reduce at the end of a frame).
+    out=tensor: OUT OF PLACE — `hdr` is left untouched on every rank (it keeps accumulating: progressive display, "reduce every
+    K spp") and the root finds the assembled frame in `out`; on the other ranks `out` is scratch.
+
+    RCCL ("nccl") reduces device tensors on the current stream.  gloo has no reduce for device tensors: there the buffer is
+    staged through host memory (the 2-ranks-on-one-GPU dry run and the CPU tests)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        if out is not None:
+            out.copy_(hdr)
+            return out
         return hdr
     if hdr.is_cuda and dist.get_backend(group) != "nccl":
         host = hdr.cpu()                                   # synchronises the current stream
         dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
         if dist.get_rank(group) == dst:
-            hdr.copy_(host)
-        return hdr
+            (out if out is not None else hdr).copy_(host)
+        return out if out is not None else hdr
+    if out is not None:
+        out.copy_(hdr)
+        dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        return out
     dist.reduce(hdr, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return hdr
 
 
 class DistributedFrame:
     """Binds a Renderer to this process's rank: torch owns the HDR buffer (so RCCL can reduce it in place) and the
-    renderer launches on a torch stream (so the collective is ordered after the render kernel).
+    renderer uses a torch stream as its context stream (so the collective is ordered after the launches, see `flush`).
 
     Lifetime: the Renderer is handed references to the tensor and the stream (`Renderer._bound`), so neither can be
     collected while the context still points at them; `close()` gives the context back its own buffer and stream."""
@@ -68,8 +78,6 @@ class DistributedFrame:
         self.r = renderer
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device_index)
-        # Each frame in flight has its own stream: the tail of one frame's render kernel (a few long paths) then
-        # overlaps the start of the next frame instead of idling the GPU.
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         W, H = renderer.image_res
         with torch.cuda.stream(self.stream):
@@ -77,33 +85,69 @@ class DistributedFrame:
             # the same stream, so the fill is ordered before them (a fill on torch's default stream would not be)
             self.hdr = torch.zeros(H * W * 3, dtype=torch.float32, device=self.device)
         self.stream.synchronize()
+        self.assembled = None                       # root's frame of the out-of-place (progressive) reduce
+        self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self._timed = False
         renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
         renderer.set_stream(self.stream.cuda_stream)
         renderer._bound = (self.hdr, self.stream)
         renderer.set_tile_partition(rank, world)
 
+    def _reduce(self, out=None):
+        if self.world > 1:
+            self.r.flush()                    # the collective is torch's own work on this stream: order it after the launches
+        self._ev[0].record(self.stream)
+        reduce_hdr(self.hdr, dst=0, out=out)
+        self._ev[1].record(self.stream)
+        self._timed = True
+
     def render_frame(self, spp):
         """reset -> accumulate(spp) on this rank's tiles -> reduce to rank 0 -> display transform on rank 0 (device).
-        Everything is enqueued on this frame's stream; with RCCL nothing here waits for the GPU."""
+        Everything is enqueued; with RCCL nothing here waits for the GPU."""
         with self.torch.cuda.stream(self.stream):
+            self.r.set_display_source(None)
             self.r.reset_framebuffer()        # zeroes the bound HDR buffer on the frame's stream
             self.r.accumulate(spp)
-            if self.world > 1:
-                self.r.flush()                # the collective below is torch's own work on this stream: order it after the launches
-            reduce_hdr(self.hdr, dst=0)
+            self._reduce()
             if self.rank == 0:
                 self.r.render_to_image_device()
+
+    def render_frame_progressive(self, spp, every):
+        """BASELINE cfg5 (1024 spp progressive): reset, then `every` samples at a time -> out-of-place reduce -> display on
+        rank 0.  Each rank's buffer keeps its own running sums; rank 0 shows the assembled frame after every reduce."""
+        with self.torch.cuda.stream(self.stream):
+            if self.assembled is None:
+                self.assembled = self.torch.zeros_like(self.hdr)
+            self.r.reset_framebuffer()
+            done = 0
+            while done < spp:
+                n = min(every, spp - done)
+                self.r.accumulate(n)
+                self._reduce(out=self.assembled)
+                if self.rank == 0:
+                    self.r.set_display_source(self.assembled.data_ptr())
+                    self.r.render_to_image_device()
+                done += n
+
+    def last_reduce_ms(self):
+        if not self._timed:
+            return 0.0
+        self._ev[1].synchronize()
+        return float(self._ev[0].elapsed_time(self._ev[1]))
 
     def fetch_hdr(self):
         """The (reduced, on rank 0) HDR buffer as a (W, H, 3) array."""
         return self.r.fetch_hdr()
 
     def synchronize(self):
+        self.r.synchronize()
         self.stream.synchronize()
 
     def close(self):
         if getattr(self, "r", None) is not None and getattr(self.r, "_bound", None) is not None:
+            self.r.synchronize()
             self.stream.synchronize()
+            self.r.set_display_source(None)
             self.r.unbind()
         self.r = None
 
@@ -118,7 +162,11 @@ class LibraryComm:
     """The library's own RCCL communicator (C ABI: de_comm_unique_id / de_comm_init / de_reduce / de_comm_destroy).
 
     `exchange(id_bytes_or_None) -> id_bytes` is any host-side broadcast of the 128-byte unique id from rank 0
-    (a file, a socket, MPI, torch.distributed.broadcast_object_list ...): the only thing the host framework provides."""
+    (a file, a socket, MPI, torch.distributed.broadcast_object_list ...): the only thing the host framework provides.
+    One communicator per rank: the launches of consecutive frames overlap inside the context (launch slots), so frames in
+    flight need no communicators of their own.  UNVERIFIED between two GPUs (no multi-GPU box was available to the builder;
+    tests/test_gpu_round2.py runs it with one rank, tests/test_a_multi_rank_gpu.py asserts RCCL's clean refusal of two ranks on
+    one device)."""
 
     def __init__(self, renderer, rank, world, exchange):
         self.r = renderer
@@ -135,7 +183,33 @@ class LibraryComm:
         if self.rank == root:
             self.r.render_to_image_device()
 
+    def render_frame_progressive(self, spp, every, root=0):
+        self.r.reset_framebuffer()
+        done = 0
+        while done < spp:
+            n = min(every, spp - done)
+            self.r.accumulate(n)
+            self.r.reduce_progressive(root)
+            if self.rank == root:
+                self.r.render_to_image_device()
+            done += n
+
+    def last_reduce_ms(self):
+        return self.r.last_reduce_ms()
+
+    def fetch_hdr(self):
+        return self.r.fetch_hdr()
+
+    def synchronize(self):
+        self.r.synchronize()
+
     def close(self):
         if self.r is not None:
             self.r.comm_destroy()
             self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -421,6 +421,26 @@ class Renderer:
         """Sum the HDR buffers of all ranks onto `root` (RCCL, in place, on the context's stream)."""
         check(self._lib.de_reduce(self._h, ctypes.c_void_p(comm) if comm else None, int(root)))
 
+    def reduce_progressive(self, root=0, comm=None):
+        """Out-of-place sum onto `root`: this rank keeps accumulating; the root displays the assembled frame (progressive mode)."""
+        check(self._lib.de_reduce_progressive(self._h, ctypes.c_void_p(comm) if comm else None, int(root)))
+
+    def last_reduce_ms(self):
+        ms = ctypes.c_float()
+        check(self._lib.de_last_reduce_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def set_display_source(self, device_ptr):
+        """Display / fetch from another [H][W][3] f32 device buffer (None: the accumulation buffer again)."""
+        check(self._lib.de_set_display_source(self._h, ctypes.c_void_p(device_ptr) if device_ptr else None))
+
+    def set_launch_slots(self, n_slots, n_big=None):
+        """Launches in flight: n_slots for small launches, n_big for big ones (1 = serial)."""
+        check(self._lib.de_set_launch_slots(self._h, int(n_slots), int(n_big if n_big is not None else min(n_slots, 3))))
+
+    def set_wave_budget(self, waves_per_cu):
+        check(self._lib.de_set_wave_budget(self._h, int(waves_per_cu)))
+
     def render_to_image_device(self):
         """Run the display transform and leave the (W, H, 3) image on the device; returns its address."""
         if not self._textures_copied:

@@ -182,7 +182,23 @@ int de_comm_unique_id(void* out128);
 int de_comm_init(de_ctx* ctx, const void* id128, int rank, int world);
 int de_comm_destroy(de_ctx* ctx);
 int de_reduce(de_ctx* ctx, void* comm, int root);
+/* Progressive display ("reduce every K spp"): like de_reduce, but OUT OF PLACE — every rank's accumulation buffer
+ * stays its own (it keeps accumulating), the root receives the assembled frame in a buffer of the library, and that buffer
+ * becomes what de_render_to_image / de_fetch_image / de_fetch_hdr read until the next de_reset.  (An in-place reduce would add
+ * the other ranks' running sums into the root's again at the next reduce.) */
+int de_reduce_progressive(de_ctx* ctx, void* comm, int root);
+/* Duration of the last de_reduce / de_reduce_progressive on the context stream (HIP events, ms). */
+int de_last_reduce_ms(de_ctx* ctx, float* ms);
+/* Display transform source: a device buffer [H][W][3] f32 to read instead of the accumulation buffer (NULL = back to it) — for
+ * hosts that run the out-of-place collective themselves (torch.distributed on a second tensor). */
+int de_set_display_source(de_ctx* ctx, const void* device_ptr);
 int de_synchronize(de_ctx* ctx);
+/* Launches in flight per context (see de_accumulate): n_slots for small launches, n_big for launches with more than 96 MB of
+ * per-sample records; 1 = every launch waits for the previous one.  Waits for the launches in flight. */
+int de_set_launch_slots(de_ctx* ctx, int n_slots, int n_big);
+/* Resident waves per CU the render kernel takes (1..20, default 20 = 5 per SIMD, all of the CU's vector registers).  A host that
+ * overlaps a collective with the next frame's render leaves room for the collective's kernel: 16 = 4 per SIMD. */
+int de_set_wave_budget(de_ctx* ctx, int waves_per_cu);
 
 /* Duration of the last de_accumulate call measured with HIP events on its launch slot (ms): from the start of its first
  * render launch to the end of its last accumulate_kernel. */

@@ -55,7 +55,7 @@ def main():
     p = o.get_params()
     for i in range(3):
         p.camera_pos[i] = pre["pos"][i]; p.look_at[i] = pre["look_at"][i]
-    up = np.array(pre["up"], np.float32); up = up / np.sqrt((up[0] * up[0] + up[1] * up[1]) + up[2] * up[2])
+    up = np.array(pre["up"], np.float32); up = (np.float32(1.0) / np.sqrt((up[0] * up[0] + up[1] * up[1]) + up[2] * up[2])) * up   # ti.Vector.normalized(): invlen * v
     for i in range(3):
         p.up[i] = float(up[i])
     p.fov = pre["fov"]; p.aspect_scale = pre["aspect_scale"]; p.exposure = pre["exposure"]; p.selected_crf = pre["crf"]

@@ -59,3 +59,46 @@ def test_ranks_on_one_gpu_match_one_rank(tmp_path, world):
     a, b = np.load(solo), np.load(multi)
     assert a.shape == (256, 128, 3) and np.isfinite(a).all() and a.max() > 0
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    # what makes an N-GPU line interpretable: per-rank render / collective times and tile counts, the launch
+    # settings, and the same steps under the other setting (serial <-> overlapping frames)
+    assert [pr["rank"] for pr in j2["per_rank"]] == list(range(world))
+    assert sum(pr["tiles_owned"] for pr in j2["per_rank"]) == (256 // 8) * (128 // 8)
+    assert all(pr["render_ms"] > 0 and pr["reduce_ms"] >= 0 for pr in j2["per_rank"])
+    assert j2["config"]["waves_per_cu"] == 20 and j2["config"]["launch_slots"] == 3
+    assert j2["alt"]["serial_frames"] is True and j2["alt"]["value"] > 0
+    assert j1["config"]["waves_per_cu"] == 20 and "alt" not in j1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_progressive_frames_on_two_ranks(tmp_path):
+    """BASELINE cfg5's mode: out-of-place reduce + display after every K spp.  The assembled frame after the last
+    reduce equals the 1-rank frame bit for bit — an in-place reduce would have counted the other ranks' early samples twice."""
+    solo, multi = str(tmp_path / "solo.npy"), str(tmp_path / "multi.npy")
+    common = [a if a != "3" else "6" for a in COMMON]                     # 6 spp, reduced after every 2
+    p1 = _run([sys.executable, "bench.py", "--gpus", "1", "--dump-hdr", solo] + common)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    port = 29700 + (os.getpid() % 1500)
+    p2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "2", "--progressive", "2", "--dump-hdr", multi] + common,
+              env_extra={"DE_DIST_BACKEND": "gloo"})
+    assert p2.returncode == 0, (p2.stdout[-2000:], p2.stderr[-4000:])
+    j2 = _json_line(p2.stdout)
+    assert j2["config"]["progressive_every"] == 2
+    a, b = np.load(solo), np.load(multi)
+    assert a.max() > 0 and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_library_communicator_refuses_two_ranks_on_one_gpu_cleanly():
+    """`bench.py --reduce lib` (de_comm_init / de_reduce inside the library) with two ranks on ONE device: RCCL refuses a
+    duplicate GPU at ncclCommInitRank; the library must turn that into an error message and a non-zero exit, not a crash or a
+    hang.  (Between two GPUs this path is unverified: no multi-GPU box was available to the builder.)"""
+    port = 29800 + (os.getpid() % 1500)
+    p = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "2", "--reduce", "lib"] + COMMON,
+             env_extra={"DE_DIST_BACKEND": "gloo", "NCCL_DEBUG": "WARN"}, timeout=420)
+    text = p.stdout + p.stderr
+    assert p.returncode != 0
+    assert "ncclCommInitRank" in text or "libdigitalearth_hip error" in text, text[-3000:]

@@ -91,7 +91,7 @@ def test_earth_viewer_preset_through_product_parser(lut_arrays):
     p = o.get_params()
     for i in range(3):
         p.camera_pos[i] = want[i]; p.look_at[i] = want[3 + i]
-    up = np.array(want[6:9], np.float32); up = up / np.sqrt((up[0] * up[0] + up[1] * up[1]) + up[2] * up[2])
+    up = np.array(want[6:9], np.float32); up = (np.float32(1.0) / np.sqrt((up[0] * up[0] + up[1] * up[1]) + up[2] * up[2])) * up   # ti.Vector.normalized(): invlen * v
     for i in range(3):
         p.up[i] = float(up[i])
     p.fov, p.aspect_scale, p.exposure, p.selected_crf, p.gamma, p.sun_angle, p.sun_path_rot = want[9], want[10], want[11], int(want[12]), want[13], want[14], want[15]
