@@ -14,6 +14,7 @@
 // single translation unit: the kernels are compiled together with the host API
 #include "render_kernel.hip"
 #include "render_kernel_v2.hip"
+#include "render_kernel_v3.hip"
 #include "aux_kernels.hip"
 
 namespace {
@@ -202,7 +203,17 @@ struct de_ctx {
     bool reduce_timing_valid = false;
     void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
     int comm_rank = 0, comm_world = 1;
-    int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip)
+    int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip), 3 = wavefront pipeline through HBM queues (render_kernel_v3.hip)
+    wf::Rec* v3_rec[wf::NQ] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage queues of render_kernel_v3 (64 B per path each)
+    uint32_t* v3_ctl = nullptr;      // two sets of 2 control words per queue (the set being filled / the set to fill next)
+    int v3_epoch[wf::NQ] = {0, 0, 0, 0, 0, 0, 0};   // completed drains per queue: parity selects the current set
+    wf::Cold* v3_cold = nullptr;     // 64 B per path
+    size_t v3_capacity = 0;          // paths the buffers hold
+    size_t v3_max_items = (size_t)1 << 27;   // paths per launch (512 B each: 68 GB at 2^27); env DE_V3_MAX_ITEMS
+    int v3_wpc = 32;                 // resident waves per CU the v3 kernels are sized for (env DE_V3_WPC)
+    int hybrid_v3_spp = 0;           // experiment (env DE_HYBRID_V3): of each de_accumulate call with variant 2, this many samples per pixel run through the v3 pipeline on another launch slot, side by side with v2
+    int launch_variant = 2;          // variant of the sub-launch being issued
+    int last_v3_slot = -1;           // the v3 pipeline has one set of queues: its launches follow each other
     de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
     int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked
 };
@@ -349,6 +360,64 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     return DE_OK;
 }
 
+// render_kernel_v3: the level-synchronous launch sequence of one batch of paths — ten launches per path vertex, each draining
+// one stage queue (render_kernel_v3.hip).  Every launch is sized to the machine, not to the queue: a block that finds its queue
+// empty leaves after one atomic.
+int v3_reserve(de_ctx* c, size_t n_items) {
+    if (n_items <= c->v3_capacity) return DE_OK;
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int i = 0; i < wf::NQ; ++i) { if (c->v3_rec[i]) hipFree(c->v3_rec[i]); c->v3_rec[i] = nullptr; }
+    if (c->v3_cold) hipFree(c->v3_cold);
+    c->v3_cold = nullptr; c->v3_capacity = 0;
+    // room for every path plus the holes the waves' last bulk reservations leave (render_kernel_v3.hip: push / close_out)
+    const size_t slack = 4u * (size_t)c->n_cus * 32u * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
+    for (int i = 0; i < wf::NQ; ++i) HIP_TRY(hipMalloc(&c->v3_rec[i], (n_items + slack) * sizeof(wf::Rec)));
+    HIP_TRY(hipMalloc(&c->v3_cold, n_items * sizeof(wf::Cold)));
+    if (!c->v3_ctl) {
+        HIP_TRY(hipMalloc(&c->v3_ctl, wf::NQ * 4 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->v3_ctl, 0, wf::NQ * 4 * sizeof(uint32_t)));
+        for (int i = 0; i < wf::NQ; ++i) c->v3_epoch[i] = 0;
+    }
+    c->v3_capacity = n_items;
+    return DE_OK;
+}
+hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream) {
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    wf::Args A;
+    A.a = a;
+    A.cold = c->v3_cold;
+    A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
+    const unsigned by_work = (unsigned)((A.n_items + DE_V3_BLOCK - 1) / DE_V3_BLOCK);
+    const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v3_wpc;
+    dim3 grid(by_work < machine ? by_work : machine), block(DE_V3_BLOCK);
+    // the control words each launch sees: per queue, the set being filled (pushes, and the drain of that queue) and the other one
+    auto bind = [&]() {
+        for (int i = 0; i < wf::NQ; ++i) {
+            A.q[i].rec = c->v3_rec[i];
+            A.q[i].ctl = c->v3_ctl + 4 * i + 2 * (c->v3_epoch[i] & 1);
+            A.q[i].ctl_next = c->v3_ctl + 4 * i + 2 * ((c->v3_epoch[i] + 1) & 1);
+        }
+    };
+#define V3_DRAIN_T(qid, k, ...) { bind(); if (clamp) hipLaunchKernelGGL((k<true>), grid, block, 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((k<false>), grid, block, 0, stream, __VA_ARGS__); c->v3_epoch[qid]++; }
+#define V3_DRAIN(qid, k, ...) { bind(); hipLaunchKernelGGL(k, grid, block, 0, stream, __VA_ARGS__); c->v3_epoch[qid]++; }
+    for (int depth = 0; depth < 25; ++depth) {
+        if (depth == 0) { bind(); if (clamp) hipLaunchKernelGGL((v3_primary_kernel<true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v3_primary_kernel<false>), grid, block, 0, stream, A, a.fc); }
+        else V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)               // path rays of this vertex
+        V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // delta tracking, gases
+        V3_DRAIN_T(wf::Q_CLOUD, v3_cloud_kernel, A)                    // delta tracking, cloud shell
+        V3_DRAIN_T(wf::Q_EVENT, v3_event_kernel, A, a.fc)              // event, light sample, branch
+        V3_DRAIN_T(wf::Q_SURF, v3_surf_kernel, A, a.fc)                // surface hits: normal, material, shadow ray
+        V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)                    // shadow rays
+        V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // ratio tracking towards the sun, gases
+        V3_DRAIN_T(wf::Q_CLOUD, v3_cloud_kernel, A)                    // ... cloud shell
+        V3_DRAIN(wf::Q_SCFIN, v3_scfin_kernel, A, a.fc)                // volume vertices: shade, next direction
+        V3_DRAIN(wf::Q_SURFFIN, v3_surffin_kernel, A, a.fc)            // surface vertices
+    }
+#undef V3_DRAIN_T
+#undef V3_DRAIN
+    return hipGetLastError();
+}
+
 // One launch on `stream`.  v2 (the default path tracer): render_kernel_v2 writes the per-sample records, then — after `pre_acc`
 // has made the stream wait for the previous launch's accumulate_kernel and for context-stream work on the HDR buffer — accumulate_kernel
 // adds them to the HDR buffer.  The other kernels read-modify-write the HDR buffer themselves: `pre_acc` runs before them.
@@ -357,7 +426,15 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a, hipStream_t stream, Pre
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
-    if (!march && c->kernel_variant == 2) {
+    if (!march && c->launch_variant == 3 && MODE == 0) {
+        hipError_t e3 = launch_v3(c, a, stream);
+        if (e3 != hipSuccess) return e3;
+        hipError_t pe = pre_acc();
+        if (pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (!march && c->launch_variant != 1) {
         // persistent waves pulling pixels from a device-wide counter: size the grid to the machine, not to the image
         hipError_t me = hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), stream);
         if (me != hipSuccess) return me;
@@ -480,12 +557,14 @@ int de_create(int device, int width, int height, de_ctx** out) {
     de_ctx* c = new de_ctx();
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
-    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] == '1') c->kernel_variant = 1; }
+    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] == '1') c->kernel_variant = 1; if (kv[0] == '3') c->kernel_variant = 3; }
     {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
         auto env_int = [](const char* name, int* v, int lo) { if (const char* e = getenv(name)) { int x = atoi(e); if (x >= lo) *v = x; } };
         env_int("DE_V2_THR", &c->tune_pend, 0); env_int("DE_V2_A", &c->tune_heavy, 0); env_int("DE_V2_B", &c->tune_b, 0);
         env_int("DE_V2_G", &c->tune_gas, 0); env_int("DE_V2_CHUNK", &c->tune_chunk, 1); env_int("DE_V2_WPC", &c->tune_wpc, 1);
         env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
+        if (const char* e3 = getenv("DE_V3_MAX_ITEMS")) { long long x = atoll(e3); if (x >= 4096) c->v3_max_items = (size_t)x; }
+        env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_HYBRID_V3", &c->hybrid_v3_spp, 0);
     }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
@@ -549,6 +628,9 @@ int de_destroy(de_ctx* c) {
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
+    for (int i = 0; i < wf::NQ; ++i) if (c->v3_rec[i]) hipFree(c->v3_rec[i]);
+    if (c->v3_ctl) hipFree(c->v3_ctl);
+    if (c->v3_cold) hipFree(c->v3_cold);
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
         LaunchSlot& s = c->slot[i];
         if (s.contrib) hipFree(s.contrib);
@@ -736,7 +818,9 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     rc = fill_render_args(c, &a);
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    const bool v2 = c->kernel_variant == 2 && !(c->p.flags & DE_FLAG_RAY_MARCHER);
+    const bool v2 = c->kernel_variant != 1 && !(c->p.flags & DE_FLAG_RAY_MARCHER);     // per-sample records + accumulate_kernel
+    const bool hybrid = c->kernel_variant == 2 && v2 && !c->count && c->hybrid_v3_spp > 0 && spp > c->hybrid_v3_spp;
+    const bool v3k = (c->kernel_variant == 3 || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
     // contribution buffer (kept <= 4 GB).  Larger requests are split here; the sample index continues from launch to launch
@@ -748,6 +832,11 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         while (cap > 1 && nt * cap * cap >= (1ull << 40)) --cap;
         if (cap < 1) cap = 1;
         if (c->tune_max_spp > 0 && cap > (unsigned long long)c->tune_max_spp) cap = (unsigned long long)c->tune_max_spp;
+        if (v3k) {   // the stage queues hold 512 B per path
+            unsigned long long cap3 = (unsigned long long)c->v3_max_items / (nt * 64ull);
+            if (cap3 < 1) cap3 = 1;
+            if (cap > cap3) cap = cap3;
+        }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
             return fail(DE_ERR_INVALID, "image too large for render_kernel_v2's 32-bit work-item index");
@@ -759,14 +848,20 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
     }
     bool first = true;
+    const int v2_part = hybrid ? spp - c->hybrid_v3_spp : (c->kernel_variant == 3 ? 0 : spp);     // samples [0, v2_part) by variant 1 / 2, the rest by v3
     for (int done = 0; done < spp && a.n_tiles > 0;) {
-        const int n = (spp - done < max_spp) ? spp - done : max_spp;
+        const bool this_v3 = v3k && done >= v2_part;
+        const int part_end = (v3k && !this_v3) ? v2_part : spp;
+        const int n = (part_end - done < max_spp) ? part_end - done : max_spp;
+        c->launch_variant = this_v3 ? 3 : c->kernel_variant;
         // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
         // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
         // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
         // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
         const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
-        const int n_cycle = (need_bytes > ((size_t)96 << 20)) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots;
+        // render_kernel_v3 has ONE set of stage queues per context and no long tail to hide: its launches run one after the other
+        const int n_cycle = (v3k && !hybrid) ? 1 : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
+        if (this_v3) { int rc3 = v3_reserve(c, (size_t)a.n_tiles * 64u * (size_t)n); if (rc3) return rc3; }
         const int si = c->next_slot % n_cycle;
         LaunchSlot& s = c->slot[si];
         if (v2) {
@@ -792,6 +887,10 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         if (s.seen_render != c->gen_render) {
             HIP_TRY(hipStreamWaitEvent(s.stream, c->ev_main, 0));
             s.seen_render = c->gen_render; s.seen_hdr = c->gen_hdr;
+        }
+        if (this_v3) {
+            if (c->last_v3_slot >= 0 && c->last_v3_slot != si) HIP_TRY(hipStreamWaitEvent(s.stream, c->slot[c->last_v3_slot].done, 0));
+            c->last_v3_slot = si;
         }
         if (first) { HIP_TRY(hipEventRecord(s.t0, s.stream)); c->t0_slot = si; first = false; }
         const int prev = c->last_slot;
@@ -939,7 +1038,7 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
     return DE_OK;
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
-    if (!c || (variant != 1 && variant != 2)) return fail(DE_ERR_INVALID, "kernel variant must be 1 or 2");
+    if (!c || variant < 1 || variant > 3) return fail(DE_ERR_INVALID, "kernel variant must be 1, 2 or 3");
     c->kernel_variant = variant;
     return DE_OK;
 }
