@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) dens_table_kernel(float* table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= DE_DENS_TABLE_N) return;
     const vec3 d = get_density((float)i * 0.5f);
-    table[i * 3u] = d.x; table[i * 3u + 1u] = d.y; table[i * 3u + 2u] = d.z;
+    table[i * DE_DENS_STRIDE] = d.x; table[i * DE_DENS_STRIDE + 1u] = d.y; table[i * DE_DENS_STRIDE + 2u] = d.z;
 }
 
 // ------------------------------------------------------------------------------------------------ display

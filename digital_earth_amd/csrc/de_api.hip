@@ -595,7 +595,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_node_val, 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, DE_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * (DE_MAX_SLOTS + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_dens_table, (size_t)DE_DENS_TABLE_N * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&c->d_dens_table, (size_t)DE_DENS_TABLE_N * DE_DENS_STRIDE * sizeof(float));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
@@ -603,7 +603,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMemsetAsync(c->d_hdr, 0, npx * 3 * sizeof(float), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(dens_table_kernel, dim3(DE_DENS_TABLE_N / 256), dim3(256), 0, c->stream, c->d_dens_table);
+        hipLaunchKernelGGL(dens_table_kernel, dim3((DE_DENS_TABLE_N + 255) / 256), dim3(256), 0, c->stream, c->d_dens_table);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {

@@ -414,6 +414,28 @@ DE_DEV vec3 get_density(float h) {                                              
     return v3(get_rayl_density(h), get_mie_density(h), get_ozone_density(h));
 }
 
+// One read of the altitude table of get_density (de_kernels.h: DE_DENS_TABLE_N entries of DE_DENS_STRIDE floats at h = i / 2 m).
+// DE_DENS_NT: with a non-temporal hint, so that the 3 MB table does not compete with the map taps for L2 lines (A/B experiment).
+DE_DEV vec3 dens_table_read(const float* table, uint32_t i) {
+#if DE_DENS_STRIDE == 4
+    typedef float de_f4v __attribute__((ext_vector_type(4)));
+    const de_f4v* e = reinterpret_cast<const de_f4v*>(table) + i;
+#ifdef DE_DENS_NT
+    const de_f4v q = __builtin_nontemporal_load(e);
+#else
+    const de_f4v q = *e;
+#endif
+    return v3(q.x, q.y, q.z);
+#else
+    const float* dt = table + (size_t)i * 3u;
+#ifdef DE_DENS_NT
+    return v3(__builtin_nontemporal_load(dt), __builtin_nontemporal_load(dt + 1), __builtin_nontemporal_load(dt + 2));
+#else
+    return v3(dt[0], dt[1], dt[2]);
+#endif
+#endif
+}
+
 // ------------------------------------------------------------------ lib/surface_rendering_models.py
 DE_DEV float disney_diffuse(float roughness, float ndl, float ndv, float ldh) {                        // :40-52
     float R_R = 2.0f * roughness * sqr(ldh);

@@ -49,7 +49,13 @@ struct LambdaNode {
 #define DE_N_NODES 512
 // Altitude table of get_density: entry i = (Rayleigh, Mie, ozone) density at h = i / 2 metres, for every f32-representable
 // altitude of a point with |pos| in [2^22, 2^23) below 131 072 m (3 MB).
+#ifndef DE_DENS_TABLE_N
 #define DE_DENS_TABLE_N 262144
+#endif
+// floats per entry: 3 (12 bytes: 9 % of the reads straddle two 128-byte lines) or 4 (16 bytes, aligned) — A/B in profiles/experiments
+#ifndef DE_DENS_STRIDE
+#define DE_DENS_STRIDE 3
+#endif
 
 struct RenderArgs {
     const FrameConsts* fc;

@@ -78,8 +78,7 @@ struct Tracer {
             const float len = de_sqrt_nr((pos.x * pos.x + pos.y * pos.y) + pos.z * pos.z);
             const float h2 = de_max(len - DE_PLANET_R, 0.0f) * 2.0f;
             if (h2 < (float)DE_DENS_TABLE_N) {
-                const float* dt = a.dens_table + (size_t)(uint32_t)(int)h2 * 3u;
-                return v3(dt[0], dt[1], dt[2]);
+                return dens_table_read(a.dens_table, (uint32_t)(int)h2);
             }
             return get_density(len - DE_PLANET_R);
         }

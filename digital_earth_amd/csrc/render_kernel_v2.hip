@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                         const float h2 = de_max(tap_len - DE_PLANET_R, 0.0f) * 2.0f;
                         const uint32_t di = (uint32_t)(int)h2;
                         dens_oob = !(h2 < (float)DE_DENS_TABLE_N);
-                        const float* dt = a.dens_table + (size_t)(dens_oob ? 0u : di) * 3u;
-                        dens_r = dt[0]; dens_m = dt[1]; dens_o = dt[2];
+                        const vec3 dtv = dens_table_read(a.dens_table, dens_oob ? 0u : di);
+                        dens_r = dtv.x; dens_m = dtv.y; dens_o = dtv.z;
                     }
 #else
                     dens_oob = gasR;

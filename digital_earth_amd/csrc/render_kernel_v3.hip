@@ -252,6 +252,86 @@ DE_DEV float sphere_trace(const RenderArgs& a, const Path& p, float land_height_
     return t;
 }
 
+#ifdef DE_V3_LDS_TILE
+// NS-1 experiment (BASELINE north star: "coalesced loads of the maps staged through LDS tiles"; profiles/experiments/README.md).
+// The primary rays of a wave are the 64 pixels of one 8x8 screen tile: the only spatially coherent taps of the whole integrator.
+// Per sphere-trace step the wave computes the bounding box of its lanes' footprints in units of 128-byte map tiles (8 x 4
+// footprint-packed entries); if it holds at most DE_V3_LDS_TILE tiles they are staged in LDS with coalesced loads (whole lines, 32
+// dwords each) and every lane reads its dword from LDS; otherwise (a wave across the map seam, grazing rays) the lanes tap the map
+// directly.  Same dword either way: results are unchanged.  st[0..3]: wave-steps, staged wave-steps, tiles staged, lanes served.
+template <bool CLAMP>
+DE_DEV float sphere_trace_lds(const RenderArgs& a, const Path& p, bool active, float land_height_scale, float escape_r, float max_ray_dist,
+                              uint32_t* s_tile, unsigned long long* st) {
+    float t = p.x[0];
+    int cnt = 0;
+    bool run = active;
+    const int lane = (int)(threadIdx.x & 63u);
+    const TexR8& T = a.topo;
+    while (__ballot(run) != 0ull) {
+        float len = 0.0f, fx = 0.0f, fy = 0.0f;
+        int i0 = 0, j0 = 0;
+        bool tap = false;
+        if (run) {
+            const vec3 Q = p.P + p.W * t;
+            len = length_nr(Q);
+            bool escaped = false;
+            if (cnt <= 100) {
+                const float b = dot(Q, p.W);
+                const float peri2 = (b < 0.0f) ? (len * len - b * b) : len * len;
+                if (peri2 > escape_r * escape_r) { t = max_ray_dist; run = false; escaped = true; }
+            }
+            if (!escaped) {
+                const vec3 n = Q * de_rcp_nr(len);
+                const vec2_ uv = sphere_UV_map(n);
+                const float x = fract_(uv.x * 1.0f) * T.wf - 0.5f, y = fract_(uv.y * 1.0f) * T.hf - 0.5f;
+                const float x0f = de_floor(x), y0f = de_floor(y);
+                fx = x - x0f; fy = y - y0f;
+                i0 = (int)x0f; j0 = (int)y0f;
+                if (CLAMP) { if (i0 < 0) { i0 = 0; fx = 0.0f; } if (j0 < 0) { j0 = 0; fy = 0.0f; } }
+                else { if (i0 < 0) i0 = T.w - 1; if (j0 < 0) j0 = T.h - 1; }
+                tap = true;
+            }
+        }
+        // bounding box of the tapping lanes, in map tiles
+        int tx = i0 >> 3, ty = j0 >> 2;
+        int xmin = tap ? tx : 0x7fffffff, xmax = tap ? tx : -1, ymin = tap ? ty : 0x7fffffff, ymax = tap ? ty : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, d)); xmax = max(xmax, __shfl_xor(xmax, d));
+            ymin = min(ymin, __shfl_xor(ymin, d)); ymax = max(ymax, __shfl_xor(ymax, d));
+        }
+        const unsigned long long m_tap = __ballot(tap);
+        uint32_t q = 0;
+        if (m_tap != 0ull) {
+            const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+            const int n_tiles = bw * bh;
+            st[0] += 1ull;
+            if (n_tiles <= DE_V3_LDS_TILE) {
+                __syncthreads();                                   // the previous step's readers are done with the staging area
+                for (int k = lane; k < n_tiles * 32; k += 64) {
+                    const int tile = k >> 5, e = k & 31;
+                    const int lx = xmin + tile % bw, ly = ymin + tile / bw;
+                    s_tile[k] = T.data[((uint32_t)ly * (uint32_t)T.tiles_x + (uint32_t)lx) * 32u + (uint32_t)e];
+                }
+                __syncthreads();
+                if (tap) q = s_tile[((ty - ymin) * bw + (tx - xmin)) * 32 + (((j0 & 3) << 3) | (i0 & 7))];
+                st[1] += 1ull; st[2] += (unsigned long long)n_tiles; st[3] += (unsigned long long)__popcll(m_tap);
+            } else if (tap) {
+                q = T.data[((uint32_t)ty * (uint32_t)T.tiles_x + (uint32_t)tx) * 32u + (uint32_t)(((j0 & 3) << 3) | (i0 & 7))];
+            }
+        }
+        if (tap) {
+            const float tex = tap_r8_finish(q, fx, fy);
+            const float sdf = len - DE_PLANET_R - land_height_scale * tex;
+            t += sdf;
+            cnt++;
+            if (t > max_ray_dist || de_abs(sdf) < t * 0.0001f || cnt >= 250) run = false;
+        }
+    }
+    return t;
+}
+#endif
+
 DE_DEV void write_contrib(const RenderArgs& a, uint32_t pid, float Ls, int node) {
     if (__builtin_isinf(Ls) || Ls != Ls || Ls < 0.0f) Ls = 0.0f;                          // pathtracer.py:466-467
     a.contrib[pid] = make_uint2(asu(Ls), (uint32_t)node);
@@ -272,6 +352,10 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_primary_kernel(wf::Args A, con
     __shared__ float s_node_val[64];
     s_node_val[threadIdx.x & 63u] = a.node_val[threadIdx.x & 63u];
     __syncthreads();
+#ifdef DE_V3_LDS_TILE
+    __shared__ uint32_t s_tile[DE_V3_LDS_TILE * 32];
+    unsigned long long lds_st[4] = {0ull, 0ull, 0ull, 0ull};
+#endif
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
     const float land_height_scale = fc.land_height_scale;
     const float escape_r = DE_PLANET_R + de_max(land_height_scale, 0.0f) + 8100.0f;
@@ -310,14 +394,25 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_primary_kernel(wf::Args A, con
             p.meta = m_make(0, node, 0, 0, 0, 0);
             p.x[5] = 0.0f;
             ray_head(p);
+#ifndef DE_V3_LDS_TILE
             const float t = sphere_trace<CLAMP>(a, p, land_height_scale, escape_r, MAX_RAY_DIST);
             target = after_sphere_trace(p, t, MAX_RAY_DIST);
+#endif
         }
+#ifdef DE_V3_LDS_TILE
+        {
+            const float t = sphere_trace_lds<CLAMP>(a, p, active, land_height_scale, escape_r, MAX_RAY_DIST, s_tile, lds_st);
+            if (active) target = after_sphere_trace(p, t, MAX_RAY_DIST);
+        }
+#endif
         push(A.q[Q_GAS], o_gas, p, target == Q_GAS);
         push(A.q[Q_CLOUD], o_cloud, p, target == Q_CLOUD);
         push(A.q[Q_EVENT], o_event, p, target == Q_EVENT);
     }
     close_out(A.q[Q_GAS], o_gas); close_out(A.q[Q_CLOUD], o_cloud); close_out(A.q[Q_EVENT], o_event);
+#ifdef DE_V3_LDS_TILE
+    if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 4; ++k) atomicAdd(&a.counters[56 + k], lds_st[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ ST: sphere trace of queued rays
@@ -381,8 +476,7 @@ struct GasStage {
         const float h2 = de_max(len - DE_PLANET_R, 0.0f) * 2.0f;
         vec3 dens;
         if (h2 < (float)DE_DENS_TABLE_N) {
-            const float* dt = a.dens_table + (size_t)(uint32_t)(int)h2 * 3u;
-            dens = v3(dt[0], dt[1], dt[2]);
+            dens = dens_table_read(a.dens_table, (uint32_t)(int)h2);
         } else {
             dens = get_density(len - DE_PLANET_R);
         }
