@@ -114,6 +114,11 @@ __global__ void __launch_bounds__(256) dens_table_kernel(float* table) {
 
 // ------------------------------------------------------------------------------------------------ display
 namespace {
+// The functions from here to openDR_transform restate the algorithm of OpenDRT v0.2.2 ("Open Display Transform", written by Jed
+// Smith, https://github.com/jedypod/open-display-transform), which the reference carries as a Taichi port in lib/OpenDRT.py under
+// the notice "License: GPL v3" (lib/OpenDRT.py:5-10).  Only the configuration the reference runs is restated (in_gamut = Rec709,
+// display_gamut = Rec709, EOTF = lin, Lp = 100; lib/OpenDRT.py:39-55); the same notice is on the oracle's restatement
+// (oracle/oracle_opendrt.h).
 DE_DEV float sdivf(float a, float b) { return (de_abs(b) < 1e-4f) ? 0.0f : a / b; }                    // lib/OpenDRT.py:92-97
 DE_DEV vec3 sdivf3f(vec3 a, float b) { return v3(sdivf(a.x, b), sdivf(a.y, b), sdivf(a.z, b)); }
 DE_DEV vec3 vdot_rows(const float* m, vec3 v) {                                                        // :86-88, v @ m

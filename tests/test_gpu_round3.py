@@ -167,3 +167,29 @@ def test_rccl_loader_failure_is_an_error_not_a_crash():
     out = subprocess.check_output([sys.executable, "-c", code],
                                   env=dict(os.environ, DE_RCCL_PATH="/nonexistent/librccl.so", DE_RCCL_STRICT="1"))
     assert b"clean error" in out
+
+
+def test_cfg3_quality2_maps_full_sample_count(Renderer, lut_arrays):
+    """BASELINE configs[2] with the map tier it names (the full-size preset tests used 4096x2048 maps and compared
+    the first 2 spp): 1920x1080, `config - florida.txt`, quality-2 maps (21600x10800 / 16200x8100), all 256 spp.  The oracle
+    renders every 97th 8x8 tile of the same frame at the full sample count; those pixels match bit for bit."""
+    from digital_earth_amd import parallel
+    from helpers import make_oracle, load_preset
+    W, H, SPP = 1920, 1080, 256
+    r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_quality=2, seed=2)
+    r.copy_textures()
+    p = load_preset("config - florida.txt")
+    r.set_camera_pos(*p["pos"]); r.set_look_at(*p["look_at"]); r.set_up(*p["up"])
+    r.set_fov(p["fov"]); r.set_aspect_scale(p["aspect_scale"]); r.set_exposure(p["exposure"])
+    r.set_crf(p["crf"]); r.set_gamma(p["gamma"]); r.set_sun_angle(p["sun_angle"]); r.set_sun_path_rot(p["sun_path_rot"])
+    for _ in range(4):
+        r.accumulate(64)                      # four launches of 64 spp, overlapping through the launch slots
+    g = r.fetch_hdr()
+    assert r.current_spp == SPP and np.isfinite(g).all() and g.max() > 0
+    o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
+    o.accumulate(SPP, 2, 11, 97)
+    mask = parallel.owned_pixel_mask(W, H, 11, 97)
+    assert mask.sum() >= 20000
+    assert (o.fetch_hdr()[mask].view(np.uint32) == g[mask].view(np.uint32)).all()
+    img = r.fetch_image()
+    assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01
