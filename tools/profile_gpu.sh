@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export DE_BIG_SLOTS=1    # one launch at a time: with several in flight the small kernels of one frame queue behind the persistent waves of the next and their durations show that wait
 cd /tmp
-BENCH="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 $*"   # one frame at a time: with two in flight the small kernels of one frame queue behind the persistent waves of the other and their durations show that wait
+BENCH="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --serial-frames $*"   # one frame at a time: with two in flight the small kernels of one frame queue behind the persistent waves of the other and their durations show that wait
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 # SQ pass 1: issue / occupancy
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU \
