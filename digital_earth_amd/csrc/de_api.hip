@@ -375,7 +375,10 @@ int v3_reserve(de_ctx* c, size_t n_items) {
     HIP_TRY(hipMalloc(&c->v3_cold, n_items * sizeof(wf::Cold)));
     if (!c->v3_ctl) {
         HIP_TRY(hipMalloc(&c->v3_ctl, wf::NQ * 4 * sizeof(uint32_t)));
+        // hipMemset runs on the null stream and may return before it has executed; the launch slots are non-blocking streams
+        // that do not wait for the null stream: make sure the control words are zero before any kernel can read them
         HIP_TRY(hipMemset(c->v3_ctl, 0, wf::NQ * 4 * sizeof(uint32_t)));
+        HIP_TRY(hipDeviceSynchronize());
         for (int i = 0; i < wf::NQ; ++i) c->v3_epoch[i] = 0;
     }
     c->v3_capacity = n_items;
@@ -387,6 +390,7 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream) {
     A.a = a;
     A.cold = c->v3_cold;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
+    A.capacity = (uint32_t)(c->v3_capacity + 4u * (size_t)c->n_cus * 32u * DE_V3_BULK);
     const unsigned by_work = (unsigned)((A.n_items + DE_V3_BLOCK - 1) / DE_V3_BLOCK);
     const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v3_wpc;
     dim3 grid(by_work < machine ? by_work : machine), block(DE_V3_BLOCK);

@@ -40,6 +40,7 @@ struct Args {
     Queue q[NQ];
     Cold* cold;
     uint32_t n_items;                             // paths of this launch
+    uint32_t capacity;                            // records each queue holds (paths + room for holes): no kernel reads past it
 };
 
 // A path inside a stage.  Record layout: v[0] = (pid, meta, rng.s0, rng.s1), v[1] = (P.xyz, W.x), v[2] = (W.yz, x0, x1),
@@ -135,7 +136,7 @@ DE_DEV bool next_chunk(uint32_t n, uint32_t* chunk, uint32_t* idx, bool* active)
 #define DE_V3_IN_CHUNK 256u
 template <typename Stage, int NT>
 DE_DEV void run_stage(const Args& A, const Queue& q, Stage& st, const int (&targets)[NT]) {
-    const uint32_t n = q.ctl[0];
+    const uint32_t n = min(q.ctl[0], A.capacity);
     const int lane = (int)(threadIdx.x & 63u);
     begin_drain(q);
     // this wave's current chunk of the queue (wave-uniform): chunk b to block b, then from the atomic cursor
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_event_kernel(wf::Args A, const
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
     const Queue q = A.q[Q_EVENT];
-    const uint32_t n = q.ctl[0];
+    const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_gas = {0u, 0u}, o_cloud = {0u, 0u}, o_scfin = {0u, 0u}, o_surf = {0u, 0u};
     begin_drain(q);
     uint32_t chunk = 0xffffffffu, idx; bool active;
@@ -684,7 +685,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_surf_kernel(wf::Args A, const 
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
     const Queue q = A.q[Q_SURF];
-    const uint32_t n = q.ctl[0];
+    const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
     const float land_height_scale = fc.land_height_scale, e = fc.normal_eps;
     begin_drain(q);
@@ -740,7 +741,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_scfin_kernel(wf::Args A, const
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
     const Queue q = A.q[Q_SCFIN];
-    const uint32_t n = q.ctl[0];
+    const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
     begin_drain(q);
     uint32_t chunk = 0xffffffffu, idx; bool active;
@@ -792,7 +793,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_surffin_kernel(wf::Args A, con
     using namespace wf;
     const RenderArgs& a = A.a;
     const Queue q = A.q[Q_SURFFIN];
-    const uint32_t n = q.ctl[0];
+    const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
     begin_drain(q);
     uint32_t chunk = 0xffffffffu, idx; bool active;
