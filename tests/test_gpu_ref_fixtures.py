@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from test_ref_fixtures import CAMERAS, GOLDEN, compare_with_fixture, per_sample
+from test_ref_fixtures import CAMERAS, GOLDEN, compare_marcher_with_fixture, compare_with_fixture, per_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -71,3 +71,20 @@ def test_hip_quality2_tier_matches_the_executed_reference(lut_arrays):
         rgb = hdr[z[cam + "_u"], z[cam + "_v"]].astype(np.float64)
         ref = z[cam + "_rgb"].astype(np.float64)
         assert np.sqrt(((rgb - ref)[same] ** 2).sum() / (ref[same] ** 2).sum()) <= 1e-4
+
+
+def test_hip_ray_marcher_matches_the_executed_reference(lut_arrays):
+    """ray_march_kernel against the reference's ray_marcher (pathtracer.py:471-685) executed under the stand-in."""
+    from digital_earth_amd.renderer import Renderer
+    z = np.load(os.path.join(GOLDEN, "ref_marcher.npz"))
+    W, H = (int(x) for x in z["image_res"])
+    r = Renderer((W, H), (0, 1, 0), seed=int(z["rng_seed"]), texture_source="synthetic", texture_size=tuple(int(x) for x in z["tier"]),
+                 synth_seed=int(z["synth_seed"]))
+    r.set_integrator("ray_marcher")
+    for cam in ("default", "florida"):
+        apply_fixture_camera(r, z, cam, lut_arrays[4])
+        rad, wl, draws, _ = per_sample(z, cam, [r.debug_samples(0)])
+        compare_marcher_with_fixture(z, cam, rad, wl, draws)
+        r.reset_framebuffer(); r.accumulate(1)
+        hdr, ref_hdr = r.fetch_hdr().astype(np.float64), z[cam + "_hdr"].astype(np.float64)
+        assert np.sqrt(((hdr - ref_hdr) ** 2).sum() / (ref_hdr ** 2).sum()) <= 1e-4

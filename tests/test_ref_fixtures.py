@@ -173,3 +173,54 @@ def test_quality2_fixture_records_the_oracles_agreement():
         same, med, q99, worst = z[cam + "_oracle_check"]
         assert len(z[cam + "_radiance"]) == 1798
         assert same >= 0.998 and med <= 1e-6 and q99 <= 3e-4 and worst <= 1e-2, (cam, same, med, q99, worst)
+
+
+def compare_marcher_with_fixture(z, cam, rad, wl, draws):
+    """ray_marcher (pathtracer.py:471-685) executed from the reference's text: deterministic apart from the wavelength, the pixel
+    jitter and the cone samples (9-12 draws per sample).  Relative error is meaningless for the dimmest samples — the step integral
+    (1 - exp(-x)) / x cancels for x -> 0 and 1e-10 radiances differ by factors — so they are bounded against the frame's mean."""
+    ref = z[cam + "_radiance"]
+    assert (draws == z[cam + "_draws"]).all() and (wl == z[cam + "_wavelength"]).all()
+    err = np.abs(rad.astype(np.float64) - ref)
+    bright = ref > 1e-3 * ref.mean()
+    assert bright.sum() > 100
+    assert np.median(err[bright] / ref[bright]) <= 2e-6 and np.quantile(err[bright] / ref[bright], 0.99) <= 1e-3
+    assert err.max() <= 1e-4 * ref.mean(), (cam, err.max(), ref.mean())
+
+
+@pytest.mark.parametrize("cam", ["default", "florida"])
+def test_oracle_ray_marcher_matches_the_executed_reference(lut_arrays, cam):
+    z = np.load(os.path.join(GOLDEN, "ref_marcher.npz"))
+    W, H = (int(x) for x in z["image_res"])
+    tw, th = (int(x) for x in z["tier"])
+    o = make_oracle(W, H, lut_arrays, synthetic_maps(tw, th, int(z["synth_seed"])))
+    p = fixture_params(z, cam, o.get_params(), lut_arrays[4])
+    p.flags |= 4                                                   # DE_FLAG_RAY_MARCHER
+    o.set_params(p)
+    rad, wl, draws, _ = per_sample(z, cam, [o.debug_samples(int(z["rng_seed"]), 0)])
+    compare_marcher_with_fixture(z, cam, rad, wl, draws)
+    o.accumulate(1, int(z["rng_seed"]))
+    hdr, ref_hdr = o.fetch_hdr().astype(np.float64), z[cam + "_hdr"].astype(np.float64)
+    assert np.sqrt(((hdr - ref_hdr) ** 2).sum() / (ref_hdr ** 2).sum()) <= 1e-4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib"), reason="the reference exists in the build container only")
+def test_leaf_fixtures_regenerate_from_the_reference(tmp_path):
+    """Provenance: tools/ref_fixtures/make.py, run now against /root/reference, reproduces the committed ref_leaves.npz bit for bit
+    (the vectors are what the reference's text computes under the stand-in — not edited, not produced by the oracle)."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = tmp_path / "repo"
+    (work / "tests" / "golden").mkdir(parents=True)
+    shutil.copytree(os.path.join(root, "tools"), work / "tools", ignore=shutil.ignore_patterns("micro", "__pycache__"))
+    for d in ("oracle", "digital_earth_amd", "include"):
+        os.symlink(os.path.join(root, d), work / d)
+    shutil.copy(os.path.join(root, "tests", "helpers.py"), work / "tests" / "helpers.py")
+    subprocess.check_call([sys.executable, str(work / "tools" / "ref_fixtures" / "make.py"), "leaves"], cwd=str(work), stdout=subprocess.DEVNULL)
+    new, old = np.load(work / "tests" / "golden" / "ref_leaves.npz"), np.load(os.path.join(GOLDEN, "ref_leaves.npz"))
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if old[k].dtype.kind == "f":
+            assert (new[k].view(np.uint32) == old[k].view(np.uint32)).all(), k
