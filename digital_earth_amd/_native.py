@@ -86,6 +86,7 @@ SYMBOLS = {
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),
     "de_last_error": (ctypes.c_char_p, []),
     "de_abi_version": (ctypes.c_int, []),
+    "de_arithmetic_contract": (ctypes.c_int, []),
 }
 
 _lib = None

@@ -544,6 +544,7 @@ extern "C" {
 
 const char* de_last_error(void) { return g_err.c_str(); }
 int de_abi_version(void) { return DE_ABI_VERSION; }
+int de_arithmetic_contract(void) { return DE_ARITHMETIC_CONTRACT; }
 
 int de_create(int device, int width, int height, de_ctx** out) {
     if (!out) return fail(DE_ERR_INVALID, "out is null");

@@ -225,6 +225,9 @@ int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* ou
 
 const char* de_last_error(void);
 int de_abi_version(void);
+/* DE_ARITHMETIC_CONTRACT of the build: which fixed f32 sequences the kernels use.  Golden vectors and the oracle are
+ * tied to it: tests refuse to compare a library with vectors of another contract. */
+int de_arithmetic_contract(void);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ def lib():
         build()
         L = ctypes.CDLL(_LIB_PATH)
         L.deo_last_error.restype = ctypes.c_char_p
+        L.deo_arithmetic_contract.restype = ctypes.c_int
         L.deo_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.deo_destroy.argtypes = [ctypes.c_void_p]
         L.deo_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]

@@ -43,7 +43,8 @@ def main():
     o = make_oracle(32, 16, L)
     p = o.get_params(); p.flags = 1; p.fixed_wavelength = 550.0; p.topo_res_override = 21600; o.set_params(p)
     o.accumulate(2, 0)
-    np.savez_compressed(os.path.join(HERE, "cfg1_32x16_2spp.npz"), hdr=o.fetch_hdr(), image=o.fetch_image(), trace0=o.debug_samples(0, 0))
+    contract = np.int32(ob.lib().deo_arithmetic_contract())      # the vectors below belong to this arithmetic contract
+    np.savez_compressed(os.path.join(HERE, "cfg1_32x16_2spp.npz"), hdr=o.fetch_hdr(), image=o.fetch_image(), trace0=o.debug_samples(0, 0), contract=contract)
     # 2. spectral + synthetic maps, default camera widened so the limb is in frame, and the florida preset
     tex = synth_texels()
     o = make_oracle(64, 32, L, tex)
