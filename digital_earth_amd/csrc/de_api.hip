@@ -1044,7 +1044,7 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
     if (!c || variant < 1 || variant > 3) return fail(DE_ERR_INVALID, "kernel variant must be 1, 2 or 3");
-    c->kernel_variant = variant;
+    c->kernel_variant = variant; c->launch_variant = variant;
     return DE_OK;
 }
 int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }
@@ -1188,6 +1188,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
     a.work_counter = c->d_work_counter + 16 * DE_MAX_SLOTS;     // a counter of its own: launches in the slots keep theirs
+    c->launch_variant = c->kernel_variant;                      // (variant 3 has no single-sample trace mode: it traces with variant 2)
     rc = join_slots(c);
     if (rc) return rc;
     HIP_TRY(launch_render<2>(c, a, c->stream, []() -> hipError_t { return hipSuccess; }));
