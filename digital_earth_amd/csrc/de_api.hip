@@ -203,17 +203,36 @@ struct de_ctx {
     bool reduce_timing_valid = false;
     void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
     int comm_rank = 0, comm_world = 1;
-    int kernel_variant = 2;      // 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip), 3 = wavefront pipeline through HBM queues (render_kernel_v3.hip)
-    wf::Rec* v3_rec[wf::NQ] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage queues of render_kernel_v3 (64 B per path each)
-    uint32_t* v3_ctl = nullptr;      // two sets of 2 control words per queue (the set being filled / the set to fill next)
-    int v3_epoch[wf::NQ] = {0, 0, 0, 0, 0, 0, 0};   // completed drains per queue: parity selects the current set
-    wf::Cold* v3_cold = nullptr;     // 64 B per path
-    size_t v3_capacity = 0;          // paths the buffers hold
-    size_t v3_max_items = (size_t)1 << 27;   // paths per launch (512 B each: 68 GB at 2^27); env DE_V3_MAX_ITEMS
-    int v3_wpc = 32;                 // resident waves per CU the v3 kernels are sized for (env DE_V3_WPC)
+    int kernel_variant = 4;      // 4 = automatic (default): large launches run the first vertex rounds in the wavefront pipeline and finish in the state machine, small ones run the state machine alone; 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip), 3 = wavefront pipeline through HBM queues (render_kernel_v3.hip)
+    // render_kernel_v3: one "pipe" = a set of stage queues + cold records.  Two pipes let two batches of paths run side by side on
+    // two launch slots, so that the tail-heavy small launches of one overlap the large launches of the other (env DE_V3_PIPES)
+    struct V3Pipe {
+        wf::Rec* rec[wf::NQ] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage queues (64 B per path each)
+        uint32_t* ctl = nullptr;      // two sets of 2 control words per queue (the set being filled / the set to fill next)
+        int epoch[wf::NQ] = {0, 0, 0, 0, 0, 0, 0};   // completed drains per queue: parity selects the current set
+        wf::Cold* cold = nullptr;     // 64 B per path
+        size_t capacity = 0;          // paths the buffers hold
+    } v3p[4];
+    int v3_pipes = 1;
+    int v3_depths = 25;              // vertex rounds run by the pipeline before render_kernel_v2 finishes the surviving paths (env DE_V3_DEPTHS; 25 = all)
+    int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
+    size_t v3_max_items = (size_t)1 << 26;   // paths per batch (512 B each: 34 GB per pipe at 2^26 = one half of a 1920x1080x64-spp frame); env DE_V3_MAX_ITEMS
+    int v3_wpc = 14;                 // waves per CU the v3 grids are sized for (env DE_V3_WPC; per class: DE_V3_WPC_ST / _GAS / _CLOUD / _FLAT).
+                                     // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
+                                     // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
+    int v3_wpc_class[4] = {0, 0, 0, 0};   // 0 = v3_wpc; index: 0 sphere trace (and primary), 1 gas, 2 cloud, 3 the straight-line stages
     int hybrid_v3_spp = 0;           // experiment (env DE_HYBRID_V3): of each de_accumulate call with variant 2, this many samples per pixel run through the v3 pipeline on another launch slot, side by side with v2
     int launch_variant = 2;          // variant of the sub-launch being issued
-    int last_v3_slot = -1;           // the v3 pipeline has one set of queues: its launches follow each other
+    int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
+    int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
+    // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3b_summary.md): two vertex rounds in the
+    // pipeline + the state machine as finisher beat the state machine alone by 4 % (default camera, 64 spp) to 47 % (limb view),
+    // with 8 waves per CU per pipe, two pipes for batches above 48 M paths and four below (small batches: more tails to overlap;
+    // large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay with
+    // the state machine and its launch slots.
+    int auto_depths = 2, auto_wpc = 8, auto_pipes = 0;
+    unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
+    int last_v3_slot[4] = {-1, -1, -1, -1};  // a pipe's launches follow each other
     de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
     int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked
 };
@@ -356,6 +375,7 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
     a->tiles = c->d_tiles; a->n_tiles = c->n_tiles; a->tiles_x = c->W / 8; a->tiles_identity = (c->tiles_world <= 1) ? 1 : 0;
     a->fixed_wavelength = (c->p.flags & DE_FLAG_FIXED_WAVELENGTH) ? 1 : 0;
     a->counters = c->d_counters; a->debug_out = c->d_scratch; a->work_counter = c->d_work_counter;   // work_counter / contrib: per launch slot, set by the caller
+    a->resume_rec = nullptr; a->resume_count = nullptr; a->resume_cold = nullptr; a->resume_capacity = 0;
     a->pend_thr = c->tune_pend; a->heavy_thr = c->tune_heavy; a->tune_b = c->tune_b; a->gas_thr = c->tune_gas; a->chunk = c->tune_chunk;
     return DE_OK;
 }
@@ -363,49 +383,60 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
 // render_kernel_v3: the level-synchronous launch sequence of one batch of paths — ten launches per path vertex, each draining
 // one stage queue (render_kernel_v3.hip).  Every launch is sized to the machine, not to the queue: a block that finds its queue
 // empty leaves after one atomic.
-int v3_reserve(de_ctx* c, size_t n_items) {
-    if (n_items <= c->v3_capacity) return DE_OK;
+int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
+    de_ctx::V3Pipe& P = c->v3p[pipe];
+    if (n_items <= P.capacity) return DE_OK;
     { int rc = sync_all(c); if (rc) return rc; }
-    for (int i = 0; i < wf::NQ; ++i) { if (c->v3_rec[i]) hipFree(c->v3_rec[i]); c->v3_rec[i] = nullptr; }
-    if (c->v3_cold) hipFree(c->v3_cold);
-    c->v3_cold = nullptr; c->v3_capacity = 0;
+    for (int i = 0; i < wf::NQ; ++i) { if (P.rec[i]) hipFree(P.rec[i]); P.rec[i] = nullptr; }
+    if (P.cold) hipFree(P.cold);
+    P.cold = nullptr; P.capacity = 0;
     // room for every path plus the holes the waves' last bulk reservations leave (render_kernel_v3.hip: push / close_out)
     const size_t slack = 4u * (size_t)c->n_cus * 32u * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
-    for (int i = 0; i < wf::NQ; ++i) HIP_TRY(hipMalloc(&c->v3_rec[i], (n_items + slack) * sizeof(wf::Rec)));
-    HIP_TRY(hipMalloc(&c->v3_cold, n_items * sizeof(wf::Cold)));
-    if (!c->v3_ctl) {
-        HIP_TRY(hipMalloc(&c->v3_ctl, wf::NQ * 4 * sizeof(uint32_t)));
+    for (int i = 0; i < wf::NQ; ++i) HIP_TRY(hipMalloc(&P.rec[i], (n_items + slack) * sizeof(wf::Rec)));
+    HIP_TRY(hipMalloc(&P.cold, n_items * sizeof(wf::Cold)));
+    if (!P.ctl) {
+        HIP_TRY(hipMalloc(&P.ctl, wf::NQ * 4 * sizeof(uint32_t)));
         // hipMemset runs on the null stream and may return before it has executed; the launch slots are non-blocking streams
         // that do not wait for the null stream: make sure the control words are zero before any kernel can read them
-        HIP_TRY(hipMemset(c->v3_ctl, 0, wf::NQ * 4 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(P.ctl, 0, wf::NQ * 4 * sizeof(uint32_t)));
         HIP_TRY(hipDeviceSynchronize());
-        for (int i = 0; i < wf::NQ; ++i) c->v3_epoch[i] = 0;
+        for (int i = 0; i < wf::NQ; ++i) P.epoch[i] = 0;
     }
-    c->v3_capacity = n_items;
+    P.capacity = n_items;
     return DE_OK;
 }
-hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream) {
+hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pipe) {
+    de_ctx::V3Pipe& P = c->v3p[pipe];
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     wf::Args A;
     A.a = a;
-    A.cold = c->v3_cold;
+    A.cold = P.cold;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
-    A.capacity = (uint32_t)(c->v3_capacity + 4u * (size_t)c->n_cus * 32u * DE_V3_BULK);
+    A.capacity = (uint32_t)(P.capacity + 4u * (size_t)c->n_cus * 32u * DE_V3_BULK);
     const unsigned by_work = (unsigned)((A.n_items + DE_V3_BLOCK - 1) / DE_V3_BLOCK);
-    const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v3_wpc;
-    dim3 grid(by_work < machine ? by_work : machine), block(DE_V3_BLOCK);
+    dim3 block(DE_V3_BLOCK), grid(1);
+    auto size_grid = [&](int cls) {
+        unsigned wpc = (unsigned)(c->v3_wpc_class[cls] > 0 ? c->v3_wpc_class[cls] : c->launch_wpc);
+        if (wpc > 32u) wpc = 32u;                     // the queues' room for holes is sized for 32 waves per CU
+        const unsigned machine = (unsigned)c->n_cus * wpc;
+        grid = dim3(by_work < machine ? by_work : machine);
+    };
     // the control words each launch sees: per queue, the set being filled (pushes, and the drain of that queue) and the other one
     auto bind = [&]() {
         for (int i = 0; i < wf::NQ; ++i) {
-            A.q[i].rec = c->v3_rec[i];
-            A.q[i].ctl = c->v3_ctl + 4 * i + 2 * (c->v3_epoch[i] & 1);
-            A.q[i].ctl_next = c->v3_ctl + 4 * i + 2 * ((c->v3_epoch[i] + 1) & 1);
+            A.q[i].rec = P.rec[i];
+            A.q[i].ctl = P.ctl + 4 * i + 2 * (P.epoch[i] & 1);
+            A.q[i].ctl_next = P.ctl + 4 * i + 2 * ((P.epoch[i] + 1) & 1);
         }
     };
-#define V3_DRAIN_T(qid, k, ...) { bind(); if (clamp) hipLaunchKernelGGL((k<true>), grid, block, 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((k<false>), grid, block, 0, stream, __VA_ARGS__); c->v3_epoch[qid]++; }
-#define V3_DRAIN(qid, k, ...) { bind(); hipLaunchKernelGGL(k, grid, block, 0, stream, __VA_ARGS__); c->v3_epoch[qid]++; }
-    for (int depth = 0; depth < 25; ++depth) {
-        if (depth == 0) { bind(); if (clamp) hipLaunchKernelGGL((v3_primary_kernel<true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v3_primary_kernel<false>), grid, block, 0, stream, A, a.fc); }
+#define V3_DRAIN_T(qid, k, ...) { size_grid(qid == wf::Q_ST ? 0 : (qid == wf::Q_CLOUD ? 2 : 3)); bind(); if (clamp) hipLaunchKernelGGL((k<true>), grid, block, 0, stream, __VA_ARGS__); else hipLaunchKernelGGL((k<false>), grid, block, 0, stream, __VA_ARGS__); P.epoch[qid]++; }
+#define V3_DRAIN(qid, k, ...) { size_grid(qid == wf::Q_GAS ? 1 : 3); bind(); hipLaunchKernelGGL(k, grid, block, 0, stream, __VA_ARGS__); P.epoch[qid]++; }
+    // Vertex rounds the pipeline runs itself; the path rays it has queued for round n_depths are finished by render_kernel_v2
+    // (resume mode): the wavefront stages are at their best while the rays are many and coherent, the megakernel when they
+    // are few, deep and divergent — every pipeline launch ends with its own tail, the megakernel has one.
+    const int n_depths = c->launch_depths;
+    for (int depth = 0; depth < n_depths; ++depth) {
+        if (depth == 0) { size_grid(0); bind(); if (clamp) hipLaunchKernelGGL((v3_primary_kernel<true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v3_primary_kernel<false>), grid, block, 0, stream, A, a.fc); }
         else V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)               // path rays of this vertex
         V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // delta tracking, gases
         V3_DRAIN_T(wf::Q_CLOUD, v3_cloud_kernel, A)                    // delta tracking, cloud shell
@@ -419,6 +450,21 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream) {
     }
 #undef V3_DRAIN_T
 #undef V3_DRAIN
+    if (n_depths < 25) {
+        bind();
+        RenderArgs b = a;
+        b.resume_rec = reinterpret_cast<const uint4*>(P.rec[wf::Q_ST]);
+        b.resume_count = A.q[wf::Q_ST].ctl;
+        b.resume_cold = reinterpret_cast<const float*>(P.cold);
+        b.resume_capacity = A.capacity;
+        hipError_t me = hipMemsetAsync(A.q[wf::Q_ST].ctl_next, 0, 2 * sizeof(uint32_t), stream);      // what begin_drain does in the pipeline's kernels
+        if (me == hipSuccess) me = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
+        if (me != hipSuccess) return me;
+        dim3 pgrid((unsigned)c->n_cus * (unsigned)c->tune_wpc), pblock(DE_V2_BLOCK);
+        if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, 0>), pgrid, pblock, 0, stream, b, b.fc);
+        else hipLaunchKernelGGL((render_kernel_v2<false, 0>), pgrid, pblock, 0, stream, b, b.fc);
+        P.epoch[wf::Q_ST]++;
+    }
     return hipGetLastError();
 }
 
@@ -431,7 +477,7 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a, hipStream_t stream, Pre
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
     if (!march && c->launch_variant == 3 && MODE == 0) {
-        hipError_t e3 = launch_v3(c, a, stream);
+        hipError_t e3 = launch_v3(c, a, stream, c->launch_pipe);
         if (e3 != hipSuccess) return e3;
         hipError_t pe = pre_acc();
         if (pe != hipSuccess) return pe;
@@ -562,7 +608,8 @@ int de_create(int device, int width, int height, de_ctx** out) {
     de_ctx* c = new de_ctx();
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
-    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] == '1') c->kernel_variant = 1; if (kv[0] == '3') c->kernel_variant = 3; }
+    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '4') c->kernel_variant = kv[0] - '0'; }
+    c->launch_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
     {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
         auto env_int = [](const char* name, int* v, int lo) { if (const char* e = getenv(name)) { int x = atoi(e); if (x >= lo) *v = x; } };
         env_int("DE_V2_THR", &c->tune_pend, 0); env_int("DE_V2_A", &c->tune_heavy, 0); env_int("DE_V2_B", &c->tune_b, 0);
@@ -570,6 +617,14 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
         if (const char* e3 = getenv("DE_V3_MAX_ITEMS")) { long long x = atoll(e3); if (x >= 4096) c->v3_max_items = (size_t)x; }
         env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_HYBRID_V3", &c->hybrid_v3_spp, 0);
+        env_int("DE_V3_PIPES", &c->v3_pipes, 1); if (c->v3_pipes > 4) c->v3_pipes = 4;
+        env_int("DE_V3_BATCHES", &c->v3_batches, 1);
+        env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;
+        env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
+        env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
+        if (const char* e4 = getenv("DE_AUTO_MIN_ITEMS")) { long long x = atoll(e4); if (x >= 0) c->auto_min_items = (unsigned long long)x; }
+        env_int("DE_V3_WPC_ST", &c->v3_wpc_class[0], 1); env_int("DE_V3_WPC_GAS", &c->v3_wpc_class[1], 1);
+        env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
     }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
@@ -633,9 +688,11 @@ int de_destroy(de_ctx* c) {
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
-    for (int i = 0; i < wf::NQ; ++i) if (c->v3_rec[i]) hipFree(c->v3_rec[i]);
-    if (c->v3_ctl) hipFree(c->v3_ctl);
-    if (c->v3_cold) hipFree(c->v3_cold);
+    for (auto& P : c->v3p) {
+        for (int i = 0; i < wf::NQ; ++i) if (P.rec[i]) hipFree(P.rec[i]);
+        if (P.ctl) hipFree(P.ctl);
+        if (P.cold) hipFree(P.cold);
+    }
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
         LaunchSlot& s = c->slot[i];
         if (s.contrib) hipFree(s.contrib);
@@ -825,7 +882,18 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     const bool v2 = c->kernel_variant != 1 && !(c->p.flags & DE_FLAG_RAY_MARCHER);     // per-sample records + accumulate_kernel
     const bool hybrid = c->kernel_variant == 2 && v2 && !c->count && c->hybrid_v3_spp > 0 && spp > c->hybrid_v3_spp;
-    const bool v3k = (c->kernel_variant == 3 || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
+    // does this call go through the wavefront pipeline, and with which settings
+    const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
+    bool pipeline = false;
+    int pipes = 1;
+    if (c->kernel_variant == 3 && v2 && !c->count) {
+        pipeline = true; pipes = c->v3_pipes; c->launch_depths = c->v3_depths; c->launch_wpc = c->v3_wpc;
+    } else if (c->kernel_variant == 4 && v2 && !c->count && call_items >= c->auto_min_items && spp >= 2) {
+        pipeline = true; c->launch_depths = c->auto_depths; c->launch_wpc = c->auto_wpc;
+        pipes = c->auto_pipes > 0 ? c->auto_pipes : ((call_items / 2ull > c->auto_two_pipe_items) ? 2 : 4);
+    }
+    const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
+    const bool v3k = (pipeline || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
     // contribution buffer (kept <= 4 GB).  Larger requests are split here; the sample index continues from launch to launch
@@ -841,6 +909,9 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             unsigned long long cap3 = (unsigned long long)c->v3_max_items / (nt * 64ull);
             if (cap3 < 1) cap3 = 1;
             if (cap > cap3) cap = cap3;
+            // two pipes: a call is cut in (at least) two batches that run side by side
+            const int nb = c->v3_batches < spp ? c->v3_batches : spp;
+            if (pipes >= 2 && !hybrid && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
@@ -853,21 +924,23 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
     }
     bool first = true;
-    const int v2_part = hybrid ? spp - c->hybrid_v3_spp : (c->kernel_variant == 3 ? 0 : spp);     // samples [0, v2_part) by variant 1 / 2, the rest by v3
+    const int v2_part = hybrid ? spp - c->hybrid_v3_spp : (pipeline ? 0 : spp);     // samples [0, v2_part) by variant 1 / 2, the rest by v3
     for (int done = 0; done < spp && a.n_tiles > 0;) {
         const bool this_v3 = v3k && done >= v2_part;
         const int part_end = (v3k && !this_v3) ? v2_part : spp;
         const int n = (part_end - done < max_spp) ? part_end - done : max_spp;
-        c->launch_variant = this_v3 ? 3 : c->kernel_variant;
+        c->launch_variant = this_v3 ? 3 : base_variant;
         // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
         // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
         // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
         // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
         const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
         // render_kernel_v3 has ONE set of stage queues per context and no long tail to hide: its launches run one after the other
-        const int n_cycle = (v3k && !hybrid) ? 1 : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
-        if (this_v3) { int rc3 = v3_reserve(c, (size_t)a.n_tiles * 64u * (size_t)n); if (rc3) return rc3; }
+        const int n_cycle = (v3k && !hybrid) ? pipes : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
         const int si = c->next_slot % n_cycle;
+        const int pipe = (v3k && !hybrid && pipes >= 2) ? si : 0;
+        c->launch_pipe = pipe;
+        if (this_v3) { int rc3 = v3_reserve(c, pipe, (size_t)a.n_tiles * 64u * (size_t)n); if (rc3) return rc3; }
         LaunchSlot& s = c->slot[si];
         if (v2) {
             const size_t need = (size_t)a.n_tiles * 64u * (size_t)n;
@@ -894,8 +967,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             s.seen_render = c->gen_render; s.seen_hdr = c->gen_hdr;
         }
         if (this_v3) {
-            if (c->last_v3_slot >= 0 && c->last_v3_slot != si) HIP_TRY(hipStreamWaitEvent(s.stream, c->slot[c->last_v3_slot].done, 0));
-            c->last_v3_slot = si;
+            if (c->last_v3_slot[pipe] >= 0 && c->last_v3_slot[pipe] != si) HIP_TRY(hipStreamWaitEvent(s.stream, c->slot[c->last_v3_slot[pipe]].done, 0));
+            c->last_v3_slot[pipe] = si;
         }
         if (first) { HIP_TRY(hipEventRecord(s.t0, s.stream)); c->t0_slot = si; first = false; }
         const int prev = c->last_slot;
@@ -1043,8 +1116,8 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
     return DE_OK;
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
-    if (!c || variant < 1 || variant > 3) return fail(DE_ERR_INVALID, "kernel variant must be 1, 2 or 3");
-    c->kernel_variant = variant; c->launch_variant = variant;
+    if (!c || variant < 1 || variant > 4) return fail(DE_ERR_INVALID, "kernel variant must be 1, 2, 3 or 4");
+    c->kernel_variant = variant; c->launch_variant = variant == 4 ? 2 : variant;
     return DE_OK;
 }
 int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }
@@ -1188,7 +1261,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
     a.work_counter = c->d_work_counter + 16 * DE_MAX_SLOTS;     // a counter of its own: launches in the slots keep theirs
-    c->launch_variant = c->kernel_variant;                      // (variant 3 has no single-sample trace mode: it traces with variant 2)
+    c->launch_variant = c->kernel_variant == 1 ? 1 : 2;         // (the pipeline has no single-sample trace mode: variants 3 and 4 trace with the state machine)
     rc = join_slots(c);
     if (rc) return rc;
     HIP_TRY(launch_render<2>(c, a, c->stream, []() -> hipError_t { return hipSuccess; }));

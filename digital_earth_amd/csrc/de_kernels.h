@@ -82,6 +82,13 @@ struct RenderArgs {
     int chunk;                    // v2: work items per counter fetch (env DE_V2_CHUNK)
     int gas_thr;                  // v2: lanes waiting in the GAS class that make its body run (env DE_V2_G)
     int tune_b;                   // v2: below this many iterating lanes everything that waits is processed (env DE_V2_B)
+    // v2 as the FINISHER of the wavefront pipeline (render_kernel_v3.hip): work items are not fresh samples but the path rays the
+    // pipeline queued for its next vertex round — 64-byte records (resume_rec, *resume_count of them, holes included) plus the
+    // paths' cold records (throughput, radiance so far).  nullptr = start from (pixel, sample) as usual.
+    const uint4* resume_rec;
+    const uint32_t* resume_count;
+    const float* resume_cold;     // 16 floats per path: thr, Ls, ...
+    uint32_t resume_capacity;
 };
 
 struct SetupArgs {

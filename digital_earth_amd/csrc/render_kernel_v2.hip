@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
     // successive launches, so the result is bit-identical to one-lane-per-pixel accumulation.
     const int lane = threadIdx.x & 63;
     const uint32_t items_per_tile = 64u * (uint32_t)a.spp_count;
-    const uint32_t total_items = (uint32_t)a.n_tiles * items_per_tile;
+    const bool resume = a.resume_rec != nullptr;        // wave-uniform: finisher of the wavefront pipeline (de_kernels.h)
+    const uint32_t total_items = resume ? min(*a.resume_count, a.resume_capacity) : (uint32_t)a.n_tiles * items_per_tile;
     uint32_t w_lo = 0, w_hi = 0;          // wave-uniform: this wave's current chunk [w_lo, w_hi)
     uint32_t w = 0;                       // this lane's current item
     // the frame constants come through a top-level `const __restrict__` kernel argument: the compiler then knows that no
@@ -743,6 +744,28 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
             if (need) {
                 if (!got) {
                     state = S_DONE;
+                } else if (resume) {
+                    // a queued path ray of the wavefront pipeline (wf::Path layout, render_kernel_v3.hip): position, direction, the ray
+                    // head computed by its last vertex (atmosphere and cloud-shell limits), RNG state, node, vertex count
+                    const uint4* r = a.resume_rec + (size_t)w * 4u;
+                    const uint4 q0 = r[0];
+                    if (q0.x != 0xffffffffu) {                     // not a hole left by a wave's bulk reservation
+                        const uint4 q1 = r[1], q2 = r[2], q3 = r[3];
+                        w = q0.x;                                  // from here on the path's own index (contribution slot)
+                        rng.s0 = q0.z; rng.s1 = q0.w; rng.draws = 0;
+                        node = (int)((q0.y >> 2) & 511u); sc = (int)((q0.y >> 11) & 31u); c_below = (int)((q0.y >> 16) & 1u);
+                        P = v3(__builtin_bit_cast(float, q1.x), __builtin_bit_cast(float, q1.y), __builtin_bit_cast(float, q1.z));
+                        D = v3(__builtin_bit_cast(float, q1.w), __builtin_bit_cast(float, q2.x), __builtin_bit_cast(float, q2.y));
+                        t = __builtin_bit_cast(float, q2.z);
+                        atm_x = __builtin_bit_cast(float, q2.w); atm_y = __builtin_bit_cast(float, q3.x);
+                        c_ts = __builtin_bit_cast(float, q3.y); c_tm = __builtin_bit_cast(float, q3.z);
+                        const float* cold = a.resume_cold + (size_t)w * 16u;
+                        thr = cold[0]; Ls = cold[1];
+                        DE_RELOAD_NODE()
+                        cnt = 0; rmo_event = 0;
+                        path_vertices = 0;
+                        state = S_ST_P;
+                    }
                 } else {
                     // (w >> 6) / spp by multiplication (a.spp_magic = floor(2^40 / spp) + 1; exact while (w >> 6) * spp < 2^40)
                     const uint32_t wq = w >> 6;

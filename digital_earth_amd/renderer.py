@@ -13,6 +13,7 @@ All device work happens in libdigitalearth_hip.so through ctypes (digital_earth_
 Taichi and no CPU implementation in this package.
 """
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -25,7 +26,9 @@ class _ScalarField:
     """Stand-in for a 0-d ti.field: `field[None]` reads, `field[None] = v` writes (earth_viewer.py:191-199,308-314)."""
 
     def __init__(self, owner, name, cast):
-        self._owner, self._name, self._cast = owner, name, cast
+        # a weak reference: the Renderer must be freed (and with it its device memory: up to tens of GB of pipeline queues) the
+        # moment the last user reference goes, not at the garbage collector's next cycle sweep
+        self._owner, self._name, self._cast = weakref.proxy(owner), name, cast
 
     def __getitem__(self, key):
         return self._cast(getattr(self._owner._params, self._name))
@@ -37,7 +40,7 @@ class _ScalarField:
 
 class _VectorField:
     def __init__(self, owner, name):
-        self._owner, self._name = owner, name
+        self._owner, self._name = weakref.proxy(owner), name
 
     def __getitem__(self, key):
         return np.array(list(getattr(self._owner._params, self._name)), dtype=np.float32)
@@ -374,7 +377,9 @@ class Renderer:
         check(self._lib.de_enable_counters(self._h, 1 if on else 0))
 
     def set_kernel_variant(self, variant):
-        """2 = wave-level state machine (default), 1 = per-lane loops; identical results."""
+        """4 = automatic (default): large launches run their first vertex rounds in the wavefront pipeline and finish in the
+        state machine; 2 = wave-level state machine only; 3 = wavefront pipeline (all rounds unless DE_V3_DEPTHS); 1 = per-lane
+        loops.  Identical results, bit for bit."""
         check(self._lib.de_set_kernel_variant(self._h, int(variant)))
 
     def counters(self):

@@ -205,8 +205,14 @@ int de_set_wave_budget(de_ctx* ctx, int waves_per_cu);
 int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);
-/* A/B hook: 2 (default) = wave-level state-machine kernel, 1 = per-lane loop kernel.  Same results, bit for bit.
- * The ray marcher always runs on variant 1.  Environment DE_KERNEL=1 selects variant 1 at de_create. */
+/* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
+ *   4 (default)  automatic: a call of >= 8 M paths runs its first two vertex rounds in the wavefront pipeline (variant 3's stage
+ *                kernels, two or four batches side by side) and the surviving paths finish in the state machine (variant 2);
+ *                smaller calls run variant 2 alone, overlapping through the launch slots
+ *   2            wave-level state machine only (render_kernel_v2.hip)
+ *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
+ *   1            per-lane loops (render_kernel.hip)
+ * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..4 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
 
 /* Debug / test hooks.

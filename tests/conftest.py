@@ -17,3 +17,11 @@ def lut_arrays():
     from digital_earth_amd import luts
     names, crf = luts.load_crfs()
     return luts.load_cie(), luts.load_srgb2spec(), luts.load_o3(), crf, names
+
+
+@pytest.fixture(autouse=True)
+def _free_device_memory_between_tests():
+    """A Renderer of a full-size frame holds tens of GB of device memory (pipeline queues): make sure the previous test's are gone."""
+    yield
+    import gc
+    gc.collect()

@@ -83,3 +83,47 @@ def test_wavefront_pipeline_deep_paths(Renderer):
         r.accumulate(4)
         out.append(r.fetch_hdr())
     assert bits_equal_fraction(out[0], out[1]) == 1.0
+
+
+@pytest.mark.parametrize("preset", [None, "config - sunset hurricane.txt"])
+def test_automatic_variant_takes_the_pipeline_for_large_calls(Renderer, preset):
+    """Variant 4 (default): a call of >= 8 M paths runs two vertex rounds in the wavefront pipeline — in two or four batches side by
+    side, each followed by the state machine as finisher of its surviving paths — and gives the bits of the state machine alone;
+    odd sample counts (uneven batches), several calls in a row (pipes reused), a tile partition."""
+    W, H = 512, 256
+    kw = dict(seed=13, texture_source="synthetic", texture_size=(2048, 1024))
+    out = {}
+    for variant in (2, 4):
+        r = Renderer((W, H), (0, 1, 0), **kw)
+        if preset:
+            _apply(r, preset)
+        r.set_kernel_variant(variant)
+        r.accumulate(64)                       # 8.4 M paths: pipeline (4 pipes: batches of 4.2 M)
+        r.accumulate(3)                        # small: state machine alone, continues the sample index
+        r.accumulate(65)                       # uneven batches: 33 + 32
+        full = r.fetch_hdr()
+        r.reset_framebuffer(); r.set_tile_partition(1, 2); r.accumulate(130)     # 8.5 M paths on half of the tiles
+        out[variant] = (full, r.fetch_hdr())
+    assert bits_equal_fraction(out[2][0], out[4][0]) == 1.0
+    assert bits_equal_fraction(out[2][1], out[4][1]) == 1.0
+    assert out[4][0].max() > 0
+
+
+def test_pipeline_with_finisher_matches_the_oracle(Renderer, lut_arrays, monkeypatch):
+    """The hand-over from the pipeline to the state machine at every possible round (DE_AUTO_DEPTHS = 1 .. 4), forced on a small
+    frame (DE_AUTO_MIN_ITEMS = 0) so that the oracle can render all of it: path rays queued for the next vertex are resumed by
+    render_kernel_v2 from their 64-byte records (position, direction, ray head, RNG state, vertex count) and cold records."""
+    W, H, SPP = 96, 48, 6
+    monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    ref = None
+    for depths in (1, 2, 3, 4):
+        monkeypatch.setenv("DE_AUTO_DEPTHS", str(depths))
+        r = Renderer((W, H), (0, 1, 0), seed=17, texture_source="synthetic", texture_size=(2048, 1024), cloud_heavy=True)
+        r.set_camera_pos(-9.0e6, 0.0, 9.0e6); r.set_fov(0.3)
+        r.accumulate(SPP)
+        got = r.fetch_hdr()
+        if ref is None:
+            o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
+            o.accumulate(SPP, 17)
+            ref = o.fetch_hdr()
+        assert bits_equal_fraction(got, ref) == 1.0, depths
