@@ -54,6 +54,8 @@ def parse():
                     help="progressive frames (BASELINE cfg5, SURVEY §8e): out-of-place reduce + display every K spp instead of once per frame")
     ap.add_argument("--waves-per-cu", type=int, default=0,
                     help="resident render waves per CU (1..20, default 20 = 5 per SIMD)")
+    ap.add_argument("--sync-frames", action="store_true",
+                    help="wait for every frame before submitting the next (profiling: frames do not overlap in the trace)")
     ap.add_argument("--serial-frames", action="store_true",
                     help="one launch at a time (launch slots = 1): the collective of frame k never waits behind frame k+1's persistent waves")
     ap.add_argument("--dump-hdr", default=None, help="rank 0: save the assembled HDR frame of the LAST step as .npy (tests)")
@@ -247,6 +249,8 @@ def main():
         ta = time.perf_counter()
         for i in range(n_steps):
             step(frames[i % len(frames)])
+            if args.sync_frames:
+                frames[i % len(frames)].r.synchronize()
         barrier()
         return time.perf_counter() - ta
 
@@ -374,7 +378,8 @@ def main():
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                     "kernel": "render_kernel_v2<false, 0>" if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
+                     "kernel": ("de_accumulate(%d): kernel variant %s — v3_* stage kernels (wavefront pipeline, first vertex rounds, batches side by side) + render_kernel_v2<false, 0> (finisher); "
+                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"))) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
                      "note": "the path is VALU-issue / divergence bound, not HBM bound (SURVEY §8d): see valu"},
         "valu": {"unit": "see fields", "loop_steps_per_sample": steps_per_sample,

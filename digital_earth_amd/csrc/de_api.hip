@@ -936,7 +936,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
         const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
         // render_kernel_v3 has ONE set of stage queues per context and no long tail to hide: its launches run one after the other
-        const int n_cycle = (v3k && !hybrid) ? pipes : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
+        const int n_cycle_want = (v3k && !hybrid) ? pipes : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
+        const int n_cycle = n_cycle_want < c->n_slots ? n_cycle_want : c->n_slots;      // never a slot the context stream does not join
         const int si = c->next_slot % n_cycle;
         const int pipe = (v3k && !hybrid && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe;

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md + hbm_traffic.json."""
-import csv, glob, json, os, sys
+"""Condense a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md + profiles/hbm_traffic.json.
+
+A frame of the bench workload is one de_accumulate(64) call.  With kernel variant 2 that is one render_kernel_v2 launch; with the
+default variant 4 it is a sequence: two batches side by side, each = the wavefront pipeline's stage kernels for two vertex rounds
+(v3_*) + render_kernel_v2 as finisher.  Counters are therefore summed over ALL render kernels of a run and divided by its number
+of frames; the frame duration is the busy span of the render kernels in the kernel trace."""
+import csv, glob, json, os, re, sys
 from collections import defaultdict
+
+RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_")
+
 
 def read_csvs(pattern):
     rows = []
@@ -10,61 +18,99 @@ def read_csvs(pattern):
             rows += list(csv.DictReader(fh))
     return rows
 
+
 def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
     root = os.path.join("gpurun_out", "prof_" + tag)
     out = ["# rocprofv3 summary `%s` (workload %s)" % (tag, workload), ""]
     stats = read_csvs(os.path.join(root, "stats", "**", "*kernel_stats.csv"))
     out += ["## kernel stats (rocprofv3 --kernel-trace --stats)", "", "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
-    for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", 0)))[:8]:
+    for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", 0)))[:14]:
         out.append("| %s | %s | %.3f | %.3f | %s |" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                       float(r["AverageNs"]) / 1e6, r.get("Percentage", "")))
     out.append("")
-    # average duration of the dominant kernel (the 64-spp launches of the production mode), for bench.py's staleness check
+    trace = read_csvs(os.path.join(root, "stats", "**", "*kernel_trace.csv"))
+    n_primary = sum(1 for r in trace if "v3_primary" in r["Kernel_Name"])
+    n_display = sum(1 for r in trace if "display_kernel" in r["Kernel_Name"])
+    n_acc = sum(1 for r in trace if "accumulate_kernel" in r["Kernel_Name"])
+    batches = max(1, round(n_primary / n_display)) if (n_primary and n_display) else 1
     kernel_ms = None
-    for r in stats:
-        if r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
-            kernel_ms = float(r["AverageNs"]) / 1e6
-    pmc = defaultdict(list)
+    if n_primary and n_display:
+        # frames run back to back: a frame = the kernels between two display_kernel launches (the bench displays every frame)
+        ev = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
+        spans, start, end = [], None, None
+        for r in ev:
+            if RENDER.search(r["Kernel_Name"]) and "<false, 1>" not in r["Kernel_Name"] and "<true, 1>" not in r["Kernel_Name"]:
+                if start is None: start = int(r["Start_Timestamp"])
+                end = max(end or 0, int(r["End_Timestamp"]))
+            elif "display_kernel" in r["Kernel_Name"] and start is not None:
+                spans.append((end - start) / 1e6); start = end = None
+        spans = [x for x in spans if x >= 0.5 * max(spans)]
+        kernel_ms = sorted(spans)[len(spans) // 2]        # the first frames of a run also allocate the pipeline's queues
+        out.append("* frames in the trace: %d (one de_accumulate(64) call each, displayed after it); first render-kernel start to last render-kernel end, median: **%.2f ms** (min %.2f, max %.2f)"
+                   % (len(spans), kernel_ms, min(spans), max(spans)))
+        out.append("* a frame = %d batches side by side, each: the wavefront pipeline's stage kernels for the first vertex rounds + render_kernel_v2 as finisher of the surviving paths" % batches)
+        rsum = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace if RENDER.search(r["Kernel_Name"])) / 1e6 / max(n_display, 1)
+        out.append("* sum of the render kernels' own durations per frame: %.1f ms (the batches overlap)" % rsum)
+        out.append("")
+    else:
+        for r in stats:
+            if r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
+                kernel_ms = float(r["AverageNs"]) / 1e6
+    # counters: sum over every render kernel of a pass, per frame of that pass
+    pmc, frames_in_pass = defaultdict(float), {}
     for d in glob.glob(os.path.join(root, "pmc_*")):
-        for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")):
-            if "render_kernel" in r.get("Kernel_Name", "") or "ray_march_kernel" in r.get("Kernel_Name", ""):
-                pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out += ["## PMC counters, render_kernel, mean per launch (64-spp launches only)", "", "| counter | mean per launch | launches |", "|---|---|---|"]
-    means = {}
-    for k, v in sorted(pmc.items()):
-        big = [x for x in v if x >= 0.5 * max(v)] if v else v   # drop the 2-spp counter launch
-        means[k] = sum(big) / max(len(big), 1)
-        out.append("| %s | %.6g | %d |" % (k, means[k], len(big)))
+        rows = [r for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")) if RENDER.search(r.get("Kernel_Name", ""))]
+        disp = defaultdict(dict)
+        for r in rows:
+            disp[r["Dispatch_Id"]]["k"] = r["Kernel_Name"]
+            disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        prim = sum(1 for v in disp.values() if "v3_primary" in v["k"])
+        if prim:
+            nf = prim / batches
+            use = [v for v in disp.values() if not re.search(r"render_kernel_v2<\w+, 1>", v["k"])]      # not the 2-spp counter launch
+        else:
+            vals = [v for v in disp.values()]
+            key = next((k for k in vals[0] if k != "k"), None) if vals else None
+            mx = max((v.get(key, 0.0) for v in vals), default=0.0)
+            use = [v for v in vals if v.get(key, 0.0) >= 0.5 * mx]                                            # the 64-spp launches
+            nf = len(use)
+        for v in use:
+            for k, x in v.items():
+                if k != "k": pmc[k] += x / max(nf, 1)
+    out += ["## PMC counters, all render kernels, per frame", "", "| counter | per frame |", "|---|---|"]
+    means = dict(pmc)
+    for k in sorted(means):
+        out.append("| %s | %.6g |" % (k, means[k]))
     out.append("")
-    if "SQ_THREAD_CYCLES_VALU" in means and "SQ_ACTIVE_INST_VALU" in means and means["SQ_ACTIVE_INST_VALU"]:
+    if means.get("SQ_ACTIVE_INST_VALU"):
         out.append("* VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = %.3f"
                    % (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"])))
-    if "SQ_ACTIVE_INST_VALU" in means and "SQ_WAVE_CYCLES" in means and means["SQ_WAVE_CYCLES"]:
+    if means.get("SQ_WAVE_CYCLES") and means.get("SQ_ACTIVE_INST_VALU"):
         out.append("* VALU issue share of wave-cycles = %.3f" % (means["SQ_ACTIVE_INST_VALU"] / means["SQ_WAVE_CYCLES"]))
     if "FETCH_SIZE" in means:
-        fetch_kb = means["FETCH_SIZE"]
-        wr_kb = means.get("WRITE_SIZE", 0.0)
+        fetch_kb, wr_kb = means["FETCH_SIZE"], means.get("WRITE_SIZE", 0.0)
         # FETCH_SIZE tallies 64 B per L2->fabric read request; every request moves a 128-byte line — for wide streams (the
-        # guide's gfx950 note) AND for this kernel's scattered dword taps (profiles/r2_fetch_calibration/README.md, measured
-        # with tools/micro/fetch_calib.hip): true read bytes = 2 x FETCH_SIZE.  Infinity-Cache hits are included.
-        out.append("* L2-miss read bytes (2 x FETCH_SIZE, calibrated): %.4g B per launch (raw counter %.4g B)" % (2 * fetch_kb * 1024, fetch_kb * 1024))
-        out.append("* write bytes (WRITE_SIZE): %.4g B per launch" % (wr_kb * 1024))
+        # guide's gfx950 note) AND for scattered dword taps (profiles/r2_fetch_calibration/README.md): true read bytes = 2 x FETCH_SIZE.
+        out.append("* L2-miss read bytes (2 x FETCH_SIZE, calibrated): %.4g B per frame (raw counter %.4g B)" % (2 * fetch_kb * 1024, fetch_kb * 1024))
+        out.append("* write bytes (WRITE_SIZE): %.4g B per frame" % (wr_kb * 1024))
         if write_json == "json":
+            miss = means.get("TCC_MISS_sum")
+            lane = (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"])) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None
             with open(os.path.join("profiles", "hbm_traffic.json"), "w") as f:
-                miss = means.get("TCC_MISS_sum")
                 json.dump({"workload": workload, "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + wr_kb * 1024,
                            "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
                            "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag, "kernel_ms": kernel_ms,
-                           "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"]) if means.get("SQ_ACTIVE_INST_VALU") and means.get("SQ_THREAD_CYCLES_VALU") else None),
-                           "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), per 64-spp launch; read bytes = 2 x FETCH_SIZE "
-                                   "(a request moves a 128-B line and is tallied as 64 B — calibrated for scattered dword loads in "
-                                   "profiles/r2_fetch_calibration). L2-miss traffic at the fabric: Infinity-Cache hits (the 3 MB altitude "
-                                   "table) are included, so this over-states HBM traffic"},
+                           "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": lane,
+                           "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), summed over every render kernel of a frame (one "
+                                   "de_accumulate(64) call: the pipeline's stage kernels and render_kernel_v2); read bytes = 2 x FETCH_SIZE (a request "
+                                   "moves a 128-B line and is tallied as 64 B: profiles/r2_fetch_calibration). L2-miss traffic at the fabric: "
+                                   "Infinity-Cache hits are included; with the pipeline it contains the queue records and cold records by design"},
                           f, indent=1)
     os.makedirs("profiles", exist_ok=True)
     with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n".join(out))
+
 
 if __name__ == "__main__":
     main(*sys.argv[1:])
