@@ -212,7 +212,17 @@ struct de_ctx {
         int epoch[wf::NQ] = {0, 0, 0, 0, 0, 0, 0};   // completed drains per queue: parity selects the current set
         wf::Cold* cold = nullptr;     // 64 B per path
         size_t capacity = 0;          // paths the buffers hold
+        // statistic for the automatic variant: records queued for vertex round 2 (holes included) of one launch, copied to pinned
+        // host memory in stream order and read by a LATER de_accumulate call — never waited for
+        uint32_t* h_round2 = nullptr;
+        hipEvent_t stat_ev = nullptr, ev_t[3] = {nullptr, nullptr, nullptr};   // stat_ev: the copy has landed; ev_t: start / pipeline done / finisher done
+        bool stat_pending = false, stat_timed = false;
+        unsigned long long stat_items = 0;
+        int stat_pipes = 1;
     } v3p[4];
+    float auto_ratio = -1.f;         // last known (records queued for round 2) / (paths started); < 0 = none yet
+    float auto_ns_per_path = -1.f;   // last known duration of a pipeline launch / its paths / the pipes running side by side
+    bool auto_deep = false;          // the deep setting is in use (hysteresis: entered above auto_deep_ns, left below 0.8 x)
     int v3_pipes = 1;
     int v3_depths = 25;              // vertex rounds run by the pipeline before render_kernel_v2 finishes the surviving paths (env DE_V3_DEPTHS; 25 = all)
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
@@ -224,14 +234,19 @@ struct de_ctx {
     int hybrid_v3_spp = 0;           // experiment (env DE_HYBRID_V3): of each de_accumulate call with variant 2, this many samples per pixel run through the v3 pipeline on another launch slot, side by side with v2
     int launch_variant = 2;          // variant of the sub-launch being issued
     int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
+    int launch_pipes = 1;            // pipes the call being issued runs side by side
     int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
     // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3b_summary.md): two vertex rounds in the
     // pipeline + the state machine as finisher beat the state machine alone by 4 % (default camera, 64 spp) to 47 % (limb view),
     // with 8 waves per CU per pipe, two pipes for batches above 48 M paths and four below (small batches: more tails to overlap;
     // large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay with
     // the state machine and its launch slots.
-    int auto_depths = 2, auto_wpc = 8, auto_pipes = 0;
+    int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
+    // views whose paths are long (limb views through thick cloud: 3.5 ns of GPU time per path against 1.6 for the default camera)
+    // keep the stage kernels full for more rounds and amortise a third, smaller batch: the pipeline then runs auto_deep_depths
+    // rounds on auto_deep_pipes pipes (env DE_AUTO_DEEP_NS in 1/100 ns per path / DE_AUTO_DEEP_DEPTHS / DE_AUTO_DEEP_PIPES)
+    int auto_deep_ns_x100 = 250, auto_deep_depths = 5, auto_deep_pipes = 3;
     int last_v3_slot[4] = {-1, -1, -1, -1};  // a pipe's launches follow each other
     de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
     int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked
@@ -401,6 +416,13 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
         HIP_TRY(hipMemset(P.ctl, 0, wf::NQ * 4 * sizeof(uint32_t)));
         HIP_TRY(hipDeviceSynchronize());
         for (int i = 0; i < wf::NQ; ++i) P.epoch[i] = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&P.h_round2), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) {
+            *P.h_round2 = 0;
+            bool ok = hipEventCreateWithFlags(&P.stat_ev, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&P.ev_t[i]) == hipSuccess;
+            if (!ok) { hipHostFree(P.h_round2); P.h_round2 = nullptr; }
+        } else P.h_round2 = nullptr;
+        (void)hipGetLastError();
     }
     P.capacity = n_items;
     return DE_OK;
@@ -435,7 +457,17 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
     // (resume mode): the wavefront stages are at their best while the rays are many and coherent, the megakernel when they
     // are few, deep and divergent — every pipeline launch ends with its own tail, the megakernel has one.
     const int n_depths = c->launch_depths;
+    const bool timed = P.h_round2 && !P.stat_pending && n_depths < 25;
+    if (timed) hipEventRecord(P.ev_t[0], stream);
+    auto note_round2 = [&]() {      // the ST queue's current set holds the count of round 2's path rays until that queue has been drained twice more
+        if (!P.h_round2 || P.stat_pending) return;
+        bind();
+        if (hipMemcpyAsync(P.h_round2, A.q[wf::Q_ST].ctl, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return;
+        if (hipEventRecord(P.stat_ev, stream) != hipSuccess) return;
+        P.stat_items = A.n_items; P.stat_pending = true; P.stat_timed = false;
+    };
     for (int depth = 0; depth < n_depths; ++depth) {
+        if (depth == 2) note_round2();
         if (depth == 0) { size_grid(0); bind(); if (clamp) hipLaunchKernelGGL((v3_primary_kernel<true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v3_primary_kernel<false>), grid, block, 0, stream, A, a.fc); }
         else V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)               // path rays of this vertex
         V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // delta tracking, gases
@@ -450,6 +482,7 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
     }
 #undef V3_DRAIN_T
 #undef V3_DRAIN
+    if (n_depths == 2) note_round2();
     if (n_depths < 25) {
         bind();
         RenderArgs b = a;
@@ -461,8 +494,10 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
         if (me == hipSuccess) me = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
         if (me != hipSuccess) return me;
         dim3 pgrid((unsigned)c->n_cus * (unsigned)c->tune_wpc), pblock(DE_V2_BLOCK);
+        if (timed && P.stat_pending) hipEventRecord(P.ev_t[1], stream);
         if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, 0>), pgrid, pblock, 0, stream, b, b.fc);
         else hipLaunchKernelGGL((render_kernel_v2<false, 0>), pgrid, pblock, 0, stream, b, b.fc);
+        if (timed && P.stat_pending) { hipEventRecord(P.ev_t[2], stream); hipEventRecord(P.stat_ev, stream); P.stat_timed = true; P.stat_pipes = c->launch_pipes; }
         P.epoch[wf::Q_ST]++;
     }
     return hipGetLastError();
@@ -622,6 +657,9 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
+        env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
+        if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
+        if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
         if (const char* e4 = getenv("DE_AUTO_MIN_ITEMS")) { long long x = atoll(e4); if (x >= 0) c->auto_min_items = (unsigned long long)x; }
         env_int("DE_V3_WPC_ST", &c->v3_wpc_class[0], 1); env_int("DE_V3_WPC_GAS", &c->v3_wpc_class[1], 1);
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
@@ -692,6 +730,9 @@ int de_destroy(de_ctx* c) {
         for (int i = 0; i < wf::NQ; ++i) if (P.rec[i]) hipFree(P.rec[i]);
         if (P.ctl) hipFree(P.ctl);
         if (P.cold) hipFree(P.cold);
+        if (P.h_round2) hipHostFree(P.h_round2);
+        if (P.stat_ev) hipEventDestroy(P.stat_ev);
+        for (int i = 0; i < 3; ++i) if (P.ev_t[i]) hipEventDestroy(P.ev_t[i]);
     }
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
         LaunchSlot& s = c->slot[i];
@@ -885,12 +926,35 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     // does this call go through the wavefront pipeline, and with which settings
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
     bool pipeline = false;
-    int pipes = 1;
+    int pipes = 1, batches = c->v3_batches;
     if (c->kernel_variant == 3 && v2 && !c->count) {
         pipeline = true; pipes = c->v3_pipes; c->launch_depths = c->v3_depths; c->launch_wpc = c->v3_wpc;
     } else if (c->kernel_variant == 4 && v2 && !c->count && call_items >= c->auto_min_items && spp >= 2) {
         pipeline = true; c->launch_depths = c->auto_depths; c->launch_wpc = c->auto_wpc;
         pipes = c->auto_pipes > 0 ? c->auto_pipes : ((call_items / 2ull > c->auto_two_pipe_items) ? 2 : 4);
+        // what earlier launches found (whichever of them have completed: nothing is waited for; results do not depend on it)
+        for (int i = 0; i < 4; ++i) {
+            de_ctx::V3Pipe& P = c->v3p[i];
+            if (P.stat_pending && hipEventQuery(P.stat_ev) == hipSuccess) {
+                if (P.stat_items) c->auto_ratio = (float)((double)*P.h_round2 / (double)P.stat_items);
+                float t_ms = 0.f;
+                if (P.stat_timed && P.stat_items && hipEventElapsedTime(&t_ms, P.ev_t[0], P.ev_t[2]) == hipSuccess && t_ms > 0.f)
+                    c->auto_ns_per_path = t_ms * 1e6f / (float)P.stat_items / (float)(P.stat_pipes > 0 ? P.stat_pipes : 1);
+                P.stat_pending = false;
+            }
+        }
+        (void)hipGetLastError();      // hipErrorNotReady of the query is not an error of this call
+        if (c->auto_ns_per_path >= 0.f) {
+            const float thr = 0.01f * (float)c->auto_deep_ns_x100;
+            if (!c->auto_deep && c->auto_ns_per_path >= thr) c->auto_deep = true;
+            else if (c->auto_deep && c->auto_ns_per_path < 0.8f * thr) c->auto_deep = false;
+        }
+        if (c->auto_deep && pipes == 2 && c->auto_deep_depths > c->auto_depths) {
+            c->launch_depths = c->auto_deep_depths;
+            if (c->auto_pipes <= 0 && pipes == 2 && c->auto_deep_pipes >= 2) pipes = c->auto_deep_pipes;
+            if (batches < pipes) batches = pipes;
+        }
+        if (getenv("DE_AUTO_TRACE")) fprintf(stderr, "[de] auto: round-2 ratio %.3f, %.2f ns per path: depths %d pipes %d\n", c->auto_ratio, c->auto_ns_per_path, c->launch_depths, pipes);
     }
     const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
     const bool v3k = (pipeline || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
@@ -910,7 +974,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (cap3 < 1) cap3 = 1;
             if (cap > cap3) cap = cap3;
             // two pipes: a call is cut in (at least) two batches that run side by side
-            const int nb = c->v3_batches < spp ? c->v3_batches : spp;
+            const int nb = batches < spp ? batches : spp;
             if (pipes >= 2 && !hybrid && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
@@ -940,7 +1004,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         const int n_cycle = n_cycle_want < c->n_slots ? n_cycle_want : c->n_slots;      // never a slot the context stream does not join
         const int si = c->next_slot % n_cycle;
         const int pipe = (v3k && !hybrid && pipes >= 2) ? si : 0;
-        c->launch_pipe = pipe;
+        c->launch_pipe = pipe; c->launch_pipes = n_cycle;
         if (this_v3) { int rc3 = v3_reserve(c, pipe, (size_t)a.n_tiles * 64u * (size_t)n); if (rc3) return rc3; }
         LaunchSlot& s = c->slot[si];
         if (v2) {

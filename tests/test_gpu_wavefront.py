@@ -87,7 +87,7 @@ def test_wavefront_pipeline_deep_paths(Renderer):
 
 @pytest.mark.parametrize("preset", [None, "config - sunset hurricane.txt"])
 def test_automatic_variant_takes_the_pipeline_for_large_calls(Renderer, preset):
-    """Variant 4 (default): a call of >= 8 M paths runs two vertex rounds in the wavefront pipeline — in two or four batches side by
+    """Variant 4 (default): a call of >= 8 M paths runs its first vertex rounds in the wavefront pipeline — in two or four batches side by
     side, each followed by the state machine as finisher of its surviving paths — and gives the bits of the state machine alone;
     odd sample counts (uneven batches), several calls in a row (pipes reused), a tile partition."""
     W, H = 512, 256
@@ -127,3 +127,24 @@ def test_pipeline_with_finisher_matches_the_oracle(Renderer, lut_arrays, monkeyp
             o.accumulate(SPP, 17)
             ref = o.fetch_hdr()
         assert bits_equal_fraction(got, ref) == 1.0, depths
+
+
+def test_automatic_variant_changes_its_settings_between_calls(Renderer, monkeypatch):
+    """The automatic variant reads the GPU time per path of EARLIER launches (without waiting for them) and moves views with long
+    paths to five pipeline rounds on three pipes.  Forced here on a small frame (every call is 'large', any measured time is
+    'long'): the first call runs the default setting, the later ones the deep one, with three uneven batches — same bits as the
+    state machine alone."""
+    W, H = 128, 64
+    monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    monkeypatch.setenv("DE_AUTO_TWO_PIPE_ITEMS", "0")
+    monkeypatch.setenv("DE_AUTO_DEEP_NS", "0")
+    out = {}
+    for variant in (2, 4):
+        r = Renderer((W, H), (0, 1, 0), seed=5, texture_source="synthetic", texture_size=(2048, 1024))
+        r.set_kernel_variant(variant)
+        for spp in (6, 7, 5, 8):
+            r.accumulate(spp)
+            r.synchronize()                    # the statistic of this call is there for the next one
+        out[variant] = r.fetch_hdr()
+    assert bits_equal_fraction(out[2], out[4]) == 1.0
+    assert out[4].max() > 0
