@@ -58,12 +58,15 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                 kernel_ms = float(r["AverageNs"]) / 1e6
     # counters: sum over every render kernel of a pass, per frame of that pass
     pmc, frames_in_pass = defaultdict(float), {}
-    for d in glob.glob(os.path.join(root, "pmc_*")):
+    per_kernel = defaultdict(lambda: defaultdict(float))      # short kernel name -> counter -> per frame; "ms:<pass>" = duration sum
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+        if not os.path.isdir(d): continue
         rows = [r for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")) if RENDER.search(r.get("Kernel_Name", ""))]
         disp = defaultdict(dict)
         for r in rows:
             disp[r["Dispatch_Id"]]["k"] = r["Kernel_Name"]
             disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            disp[r["Dispatch_Id"]]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         prim = sum(1 for v in disp.values() if "v3_primary" in v["k"])
         if prim:
             nf = prim / batches
@@ -75,8 +78,12 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
             use = [v for v in vals if v.get(key, 0.0) >= 0.5 * mx]                                            # the 64-spp launches
             nf = len(use)
         for v in use:
+            short = re.sub(r"^void ", "", v["k"]).split("(")[0]
             for k, x in v.items():
-                if k != "k": pmc[k] += x / max(nf, 1)
+                if k == "ms": per_kernel[short]["ms:" + os.path.basename(d)] += x / max(nf, 1)
+                elif k != "k":
+                    pmc[k] += x / max(nf, 1)
+                    per_kernel[short][k] += x / max(nf, 1)
     out += ["## PMC counters, all render kernels, per frame", "", "| counter | per frame |", "|---|---|"]
     means = dict(pmc)
     for k in sorted(means):
@@ -87,6 +94,19 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                    % (means["SQ_THREAD_CYCLES_VALU"] / (64.0 * means["SQ_ACTIVE_INST_VALU"])))
     if means.get("SQ_WAVE_CYCLES") and means.get("SQ_ACTIVE_INST_VALU"):
         out.append("* VALU issue share of wave-cycles = %.3f" % (means["SQ_ACTIVE_INST_VALU"] / means["SQ_WAVE_CYCLES"]))
+    if len(per_kernel) > 1 and means.get("SQ_INSTS_VALU"):
+        out += ["", "## The same counters by kernel, per frame", "",
+                "| kernel | launches' duration, ms (sum; batches overlap) | VALU wave-instructions | share | lane utilisation | L2 requests | L2 hit | read GB (2 x FETCH_SIZE) | write GB | fabric TB/s while it runs |",
+                "|---|---|---|---|---|---|---|---|---|---|"]
+        for k, c in sorted(per_kernel.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0.0)):
+            hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
+            rd, wr = 2 * c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+            ms_f = c.get("ms:pmc_fetch", 0.0)
+            out.append("| `%s` | %.1f | %.3g | %.1f %% | %.3f | %.3g | %.1f %% | %.1f | %.1f | %.2f |" % (
+                k, c.get("ms:pmc_sq1", 0.0), c.get("SQ_INSTS_VALU", 0.0), 100 * c.get("SQ_INSTS_VALU", 0.0) / means["SQ_INSTS_VALU"],
+                c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(64.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0), 1.0), c.get("TCP_TCC_READ_REQ_sum", 0.0),
+                100 * hit / max(hit + miss, 1.0), rd / 1e9, wr / 1e9, (rd + wr) / 1e12 / max(ms_f / 1e3, 1e-9)))
+        out.append("")
     if "FETCH_SIZE" in means:
         fetch_kb, wr_kb = means["FETCH_SIZE"], means.get("WRITE_SIZE", 0.0)
         # FETCH_SIZE tallies 64 B per L2->fabric read request; every request moves a 128-byte line — for wide streams (the
