@@ -221,6 +221,20 @@ struct de_ctx {
         int stat_pipes = 1;
     } v3p[4];
     float auto_ratio = -1.f;         // last known (records queued for round 2) / (paths started); < 0 = none yet
+    // Calls between auto_min_items and the two-pipe size (a rank's share of a tile partition, accumulate(16)): on light views the state
+    // machine alone is 2-10 % faster, on heavier ones the pipeline (four pipes) 25-50 % — and no cheap statistic separates the two
+    // (profiles/experiments).  So the context measures: eight such calls on the state machine, eight on the pipeline; the time from
+    // the completion of the third to the completion of the eighth, per path, is what a caller sees of either kernel whatever its
+    // calling pattern (overlapping frames or one call at a time).  The faster one (the pipeline must win by 3 %: it costs memory)
+    // is kept for auto_mid_keep calls, then both are measured again.  Nothing is waited for: the decision is taken by the first call
+    // that finds the timestamps there.  env DE_AUTO_MID: 0 = as described, 1 = always the pipeline, 2 = never; DE_AUTO_MID_KEEP
+    int auto_mid_mode = 0, auto_mid_keep = 1024;
+    bool auto_mid_pipeline = false;
+    hipEvent_t mid_a[2] = {nullptr, nullptr}, mid_b[2] = {nullptr, nullptr};   // completion of call 3 / call 8 of a measuring phase
+    unsigned long long mid_items[2] = {0, 0};      // paths of calls 4..8
+    bool mid_b_recorded[2] = {false, false};
+    int mid_phase = 0, mid_calls = 0;        // 0: measuring the state machine, 1: measuring the pipeline, 2: decided
+    float mid_ns[2] = {-1.f, -1.f};          // last measurement, ns per path: [0] state machine, [1] pipeline
     float auto_ns_per_path = -1.f;   // last known duration of a pipeline launch / its paths / the pipes running side by side
     bool auto_deep = false;          // the deep setting is in use (hysteresis: entered above auto_deep_ns, left below 0.8 x)
     int v3_pipes = 1;
@@ -657,6 +671,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 0); env_int("DE_AUTO_MID_KEEP", &c->auto_mid_keep, 1);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -683,6 +698,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
             if (e == hipSuccess) e = hipEventCreate(&s.t1);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) { e = hipEventCreate(&c->mid_a[i]); if (e == hipSuccess) e = hipEventCreate(&c->mid_b[i]); }
     }
     if (e == hipSuccess) e = hipMalloc(&c->d_hdr_own, npx * 3 * sizeof(float));
     c->d_hdr = c->d_hdr_own;
@@ -743,6 +759,7 @@ int de_destroy(de_ctx* c) {
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (c->ev_main) hipEventDestroy(c->ev_main);
+    for (int i = 0; i < 2; ++i) { if (c->mid_a[i]) hipEventDestroy(c->mid_a[i]); if (c->mid_b[i]) hipEventDestroy(c->mid_b[i]); }
     if (c->ev_r0) hipEventDestroy(c->ev_r0);
     if (c->ev_r1) hipEventDestroy(c->ev_r1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -925,13 +942,12 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     const bool hybrid = c->kernel_variant == 2 && v2 && !c->count && c->hybrid_v3_spp > 0 && spp > c->hybrid_v3_spp;
     // does this call go through the wavefront pipeline, and with which settings
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
-    bool pipeline = false;
+    bool pipeline = false, mid_call = false;
+    int mid_idx = -1;                 // index of this call in a measuring phase of the mid-size policy
     int pipes = 1, batches = c->v3_batches;
     if (c->kernel_variant == 3 && v2 && !c->count) {
         pipeline = true; pipes = c->v3_pipes; c->launch_depths = c->v3_depths; c->launch_wpc = c->v3_wpc;
     } else if (c->kernel_variant == 4 && v2 && !c->count && call_items >= c->auto_min_items && spp >= 2) {
-        pipeline = true; c->launch_depths = c->auto_depths; c->launch_wpc = c->auto_wpc;
-        pipes = c->auto_pipes > 0 ? c->auto_pipes : ((call_items / 2ull > c->auto_two_pipe_items) ? 2 : 4);
         // what earlier launches found (whichever of them have completed: nothing is waited for; results do not depend on it)
         for (int i = 0; i < 4; ++i) {
             de_ctx::V3Pipe& P = c->v3p[i];
@@ -943,18 +959,50 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
                 P.stat_pending = false;
             }
         }
-        (void)hipGetLastError();      // hipErrorNotReady of the query is not an error of this call
-        if (c->auto_ns_per_path >= 0.f) {
-            const float thr = 0.01f * (float)c->auto_deep_ns_x100;
-            if (!c->auto_deep && c->auto_ns_per_path >= thr) c->auto_deep = true;
-            else if (c->auto_deep && c->auto_ns_per_path < 0.8f * thr) c->auto_deep = false;
+        (void)hipGetLastError();      // hipErrorNotReady of a query is not an error of this call
+        const bool two_pipe_size = call_items / 2ull > c->auto_two_pipe_items;
+        mid_call = !two_pipe_size && c->auto_pipes <= 0;
+        if (mid_call) {
+            if (c->auto_mid_mode == 1) c->auto_mid_pipeline = true;
+            else if (c->auto_mid_mode == 2) c->auto_mid_pipeline = false;
+            else {
+                if (c->mid_phase == 0 && c->mid_calls >= 8) { c->mid_phase = 1; c->mid_calls = 0; }
+                else if (c->mid_phase == 1 && c->mid_calls >= 8 && c->mid_b_recorded[0] && c->mid_b_recorded[1] && hipEventQuery(c->mid_b[1]) == hipSuccess) {
+                    float t0 = 0.f, t1 = 0.f;
+                    if (hipEventElapsedTime(&t0, c->mid_a[0], c->mid_b[0]) == hipSuccess && hipEventElapsedTime(&t1, c->mid_a[1], c->mid_b[1]) == hipSuccess
+                        && c->mid_items[0] && c->mid_items[1]) {
+                        c->mid_ns[0] = t0 * 1e6f / (float)c->mid_items[0];
+                        c->mid_ns[1] = t1 * 1e6f / (float)c->mid_items[1];
+                        c->auto_mid_pipeline = c->mid_ns[1] < 0.97f * c->mid_ns[0];
+                    } else c->auto_mid_pipeline = false;
+                    c->mid_phase = 2; c->mid_calls = 0;
+                } else if (c->mid_phase == 2 && c->mid_calls >= c->auto_mid_keep) {
+                    c->mid_phase = 0; c->mid_calls = 0;
+                    c->mid_items[0] = c->mid_items[1] = 0; c->mid_b_recorded[0] = c->mid_b_recorded[1] = false;
+                }
+                (void)hipGetLastError();
+                if (c->mid_phase == 0) c->auto_mid_pipeline = false;
+                else if (c->mid_phase == 1) c->auto_mid_pipeline = true;
+                mid_idx = c->mid_calls++;
+            }
         }
-        if (c->auto_deep && pipes == 2 && c->auto_deep_depths > c->auto_depths) {
-            c->launch_depths = c->auto_deep_depths;
-            if (c->auto_pipes <= 0 && pipes == 2 && c->auto_deep_pipes >= 2) pipes = c->auto_deep_pipes;
-            if (batches < pipes) batches = pipes;
+        if (two_pipe_size || c->auto_pipes > 0 || c->auto_mid_pipeline) {
+            pipeline = true; c->launch_depths = c->auto_depths; c->launch_wpc = c->auto_wpc;
+            pipes = c->auto_pipes > 0 ? c->auto_pipes : (two_pipe_size ? 2 : 4);
+            if (c->auto_ns_per_path >= 0.f) {
+                const float thr = 0.01f * (float)c->auto_deep_ns_x100;
+                if (!c->auto_deep && c->auto_ns_per_path >= thr) c->auto_deep = true;
+                else if (c->auto_deep && c->auto_ns_per_path < 0.8f * thr) c->auto_deep = false;
+            }
+            if (c->auto_deep && pipes == 2 && c->auto_deep_depths > c->auto_depths) {
+                c->launch_depths = c->auto_deep_depths;
+                if (c->auto_pipes <= 0 && c->auto_deep_pipes >= 2) pipes = c->auto_deep_pipes;
+                if (batches < pipes) batches = pipes;
+            }
         }
-        if (getenv("DE_AUTO_TRACE")) fprintf(stderr, "[de] auto: round-2 ratio %.3f, %.2f ns per path: depths %d pipes %d\n", c->auto_ratio, c->auto_ns_per_path, c->launch_depths, pipes);
+        if (getenv("DE_AUTO_TRACE"))
+            fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d\n",
+                    call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes);
     }
     const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
     const bool v3k = (pipeline || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
@@ -1053,7 +1101,15 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         c->last_slot = si;
         c->next_slot = (si + 1) % n_cycle;
         done += n;
-        if (done >= spp) { HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true; }
+        if (done >= spp) {
+            HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true;
+            if (mid_call && mid_idx >= 0 && c->mid_phase < 2) {
+                const int m = c->mid_phase;
+                if (mid_idx == 2) HIP_TRY(hipEventRecord(c->mid_a[m], s.stream));
+                if (mid_idx >= 3 && mid_idx <= 7) c->mid_items[m] += call_items;
+                if (mid_idx == 7) { HIP_TRY(hipEventRecord(c->mid_b[m], s.stream)); c->mid_b_recorded[m] = true; }
+            }
+        }
     }
     c->current_spp += spp;
     return DE_OK;

@@ -206,10 +206,12 @@ int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);
 /* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
- *   4 (default)  automatic: a call of >= 8 M paths runs its first three vertex rounds in the wavefront pipeline (variant 3's stage
- *                kernels, two or four batches side by side) and the surviving paths finish in the state machine (variant 2);
- *                smaller calls run variant 2 alone, overlapping through the launch slots.  Views with long paths (GPU time per
- *                path of EARLIER calls, read without waiting) get five rounds and three batches; the choice moves time, not bits
+ *   4 (default)  automatic: a large call runs its first three vertex rounds in the wavefront pipeline (variant 3's stage kernels,
+ *                batches side by side) and the surviving paths finish in the state machine (variant 2).  Large = more than 96 M
+ *                paths: always (two batches; views with long paths — GPU time per path of EARLIER calls, read without waiting —
+ *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the context times
+ *                eight calls on either kernel and keeps the faster one for 1024 calls.  Smaller calls run variant 2 alone,
+ *                overlapping through the launch slots.  The choices move time, never bits
  *   2            wave-level state machine only (render_kernel_v2.hip)
  *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
  *   1            per-lane loops (render_kernel.hip)

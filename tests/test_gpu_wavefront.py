@@ -86,10 +86,12 @@ def test_wavefront_pipeline_deep_paths(Renderer):
 
 
 @pytest.mark.parametrize("preset", [None, "config - sunset hurricane.txt"])
-def test_automatic_variant_takes_the_pipeline_for_large_calls(Renderer, preset):
+def test_automatic_variant_takes_the_pipeline_for_large_calls(Renderer, preset, monkeypatch):
     """Variant 4 (default): a call of >= 8 M paths runs its first vertex rounds in the wavefront pipeline — in two or four batches side by
     side, each followed by the state machine as finisher of its surviving paths — and gives the bits of the state machine alone;
-    odd sample counts (uneven batches), several calls in a row (pipes reused), a tile partition."""
+    odd sample counts (uneven batches), several calls in a row (pipes reused), a tile partition.  (Calls of this size take the
+    pipeline only for views with long paths: DE_AUTO_MID=1 makes them take it always.)"""
+    monkeypatch.setenv("DE_AUTO_MID", "1")
     W, H = 512, 256
     kw = dict(seed=13, texture_source="synthetic", texture_size=(2048, 1024))
     out = {}
@@ -115,6 +117,7 @@ def test_pipeline_with_finisher_matches_the_oracle(Renderer, lut_arrays, monkeyp
     render_kernel_v2 from their 64-byte records (position, direction, ray head, RNG state, vertex count) and cold records."""
     W, H, SPP = 96, 48, 6
     monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    monkeypatch.setenv("DE_AUTO_MID", "1")
     ref = None
     for depths in (1, 2, 3, 4):
         monkeypatch.setenv("DE_AUTO_DEPTHS", str(depths))
@@ -145,6 +148,26 @@ def test_automatic_variant_changes_its_settings_between_calls(Renderer, monkeypa
         for spp in (6, 7, 5, 8):
             r.accumulate(spp)
             r.synchronize()                    # the statistic of this call is there for the next one
+        out[variant] = r.fetch_hdr()
+    assert bits_equal_fraction(out[2], out[4]) == 1.0
+    assert out[4].max() > 0
+
+
+def test_automatic_variant_moves_mid_size_calls_between_the_kernels(Renderer, monkeypatch):
+    """Calls between 8 M paths and the two-pipe size are measured on both kernels — eight calls on the state machine, eight on the
+    pipeline (four pipes), the faster one kept (here for two calls only, then measured again).  Whatever the timestamps say, the
+    frame has the bits of the state machine alone."""
+    W, H = 128, 64
+    monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    monkeypatch.setenv("DE_AUTO_MID_KEEP", "2")
+    out = {}
+    for variant in (2, 4):
+        r = Renderer((W, H), (0, 1, 0), seed=9, texture_source="synthetic", texture_size=(2048, 1024))
+        r.set_kernel_variant(variant)
+        for i in range(30):
+            r.accumulate(3 + i % 5)
+            if i % 3 == 0:
+                r.synchronize()
         out[variant] = r.fetch_hdr()
     assert bits_equal_fraction(out[2], out[4]) == 1.0
     assert out[4].max() > 0
