@@ -240,7 +240,7 @@ struct de_ctx {
     int v3_pipes = 1;
     int v3_depths = 25;              // vertex rounds run by the pipeline before render_kernel_v2 finishes the surviving paths (env DE_V3_DEPTHS; 25 = all)
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
-    size_t v3_max_items = (size_t)1 << 26;   // paths per batch (512 B each: 34 GB per pipe at 2^26 = one half of a 1920x1080x64-spp frame); env DE_V3_MAX_ITEMS
+    size_t v3_max_items = (size_t)1 << 27;   // paths per batch (512 B each: 68 GB per pipe at 2^27 = a whole 1920x1080x64-spp frame; v3_reserve asks the device first and the batch shrinks when there is no room); env DE_V3_MAX_ITEMS
     int v3_wpc = 14;                 // waves per CU the v3 grids are sized for (env DE_V3_WPC; per class: DE_V3_WPC_ST / _GAS / _CLOUD / _FLAT).
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
                                      // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
@@ -412,6 +412,8 @@ int fill_render_args(de_ctx* c, RenderArgs* a) {
 // render_kernel_v3: the level-synchronous launch sequence of one batch of paths — ten launches per path vertex, each draining
 // one stage queue (render_kernel_v3.hip).  Every launch is sized to the machine, not to the queue: a block that finds its queue
 // empty leaves after one atomic.
+// Returns DE_OK, an error, or V3_NO_MEMORY: the device does not have room for queues of this size (the caller shrinks the batch).
+static const int V3_NO_MEMORY = 1000;
 int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     de_ctx::V3Pipe& P = c->v3p[pipe];
     if (n_items <= P.capacity) return DE_OK;
@@ -421,8 +423,20 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     P.cold = nullptr; P.capacity = 0;
     // room for every path plus the holes the waves' last bulk reservations leave (render_kernel_v3.hip: push / close_out)
     const size_t slack = 4u * (size_t)c->n_cus * 32u * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
-    for (int i = 0; i < wf::NQ; ++i) HIP_TRY(hipMalloc(&P.rec[i], (n_items + slack) * sizeof(wf::Rec)));
-    HIP_TRY(hipMalloc(&P.cold, n_items * sizeof(wf::Cold)));
+    // 512 B per path: ask first — other contexts, the host framework and the next pipe want memory too (8 GB stay free)
+    size_t free_b = 0, total_b = 0;
+    const size_t need_b = (size_t)wf::NQ * (n_items + slack) * sizeof(wf::Rec) + n_items * sizeof(wf::Cold);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need_b + ((size_t)8 << 30)) return V3_NO_MEMORY;
+    bool ok = true;
+    for (int i = 0; i < wf::NQ && ok; ++i) ok = hipMalloc(&P.rec[i], (n_items + slack) * sizeof(wf::Rec)) == hipSuccess;
+    if (ok) ok = hipMalloc(&P.cold, n_items * sizeof(wf::Cold)) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int i = 0; i < wf::NQ; ++i) { if (P.rec[i]) hipFree(P.rec[i]); P.rec[i] = nullptr; }
+        if (P.cold) hipFree(P.cold);
+        P.cold = nullptr;
+        return V3_NO_MEMORY;
+    }
     if (!P.ctl) {
         HIP_TRY(hipMalloc(&P.ctl, wf::NQ * 4 * sizeof(uint32_t)));
         // hipMemset runs on the null stream and may return before it has executed; the launch slots are non-blocking streams
@@ -996,13 +1010,12 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             }
             if (c->auto_deep && pipes == 2 && c->auto_deep_depths > c->auto_depths) {
                 c->launch_depths = c->auto_deep_depths;
-                if (c->auto_pipes <= 0 && c->auto_deep_pipes >= 2) pipes = c->auto_deep_pipes;
-                if (batches < pipes) batches = pipes;
+                if (c->auto_pipes <= 0 && c->auto_deep_pipes >= 2) { pipes = c->auto_deep_pipes; if (batches < pipes) batches = pipes; }
             }
         }
         if (getenv("DE_AUTO_TRACE"))
-            fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d\n",
-                    call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes);
+            fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d batches %d\n",
+                    call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
     const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
     const bool v3k = (pipeline || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
@@ -1038,10 +1051,9 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     bool first = true;
     const int v2_part = hybrid ? spp - c->hybrid_v3_spp : (pipeline ? 0 : spp);     // samples [0, v2_part) by variant 1 / 2, the rest by v3
     for (int done = 0; done < spp && a.n_tiles > 0;) {
-        const bool this_v3 = v3k && done >= v2_part;
+        bool this_v3 = v3k && done >= v2_part;
         const int part_end = (v3k && !this_v3) ? v2_part : spp;
-        const int n = (part_end - done < max_spp) ? part_end - done : max_spp;
-        c->launch_variant = this_v3 ? 3 : base_variant;
+        int n = (part_end - done < max_spp) ? part_end - done : max_spp;
         // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
         // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
         // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
@@ -1053,7 +1065,18 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         const int si = c->next_slot % n_cycle;
         const int pipe = (v3k && !hybrid && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle;
-        if (this_v3) { int rc3 = v3_reserve(c, pipe, (size_t)a.n_tiles * 64u * (size_t)n); if (rc3) return rc3; }
+        if (this_v3) {
+            // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),
+            // and a batch of one sample per pixel that still does not fit runs on the state machine
+            int rc3 = v3_reserve(c, pipe, (size_t)a.n_tiles * 64u * (size_t)n);
+            while (rc3 == V3_NO_MEMORY && n > 1) {
+                n = (n + 1) / 2; max_spp = n;
+                rc3 = v3_reserve(c, pipe, (size_t)a.n_tiles * 64u * (size_t)n);
+            }
+            if (rc3 == V3_NO_MEMORY) { this_v3 = false; rc3 = DE_OK; }
+            if (rc3) return rc3;
+        }
+        c->launch_variant = this_v3 ? 3 : base_variant;
         LaunchSlot& s = c->slot[si];
         if (v2) {
             const size_t need = (size_t)a.n_tiles * 64u * (size_t)n;
