@@ -171,3 +171,23 @@ def test_automatic_variant_moves_mid_size_calls_between_the_kernels(Renderer, mo
         out[variant] = r.fetch_hdr()
     assert bits_equal_fraction(out[2], out[4]) == 1.0
     assert out[4].max() > 0
+
+
+@pytest.mark.parametrize("budget", [20000, 5000])
+def test_pipeline_batches_shrink_when_the_queues_do_not_fit(Renderer, monkeypatch, budget):
+    """The pipeline's queues take 512 B per path of a batch; `v3_reserve` asks the device for room first.  Pretend (DE_V3_TEST_BUDGET)
+    that queues for more than 20000 paths do not fit: a call of 65536 paths is cut into batches of 2 samples per pixel; with 5000 not
+    even one sample per pixel (8192 paths) fits and the call runs on the state machine.  Same bits either way."""
+    W, H = 128, 64
+    monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    monkeypatch.setenv("DE_AUTO_MID", "1")
+    monkeypatch.setenv("DE_V3_TEST_BUDGET", str(budget))
+    out = {}
+    for variant in (2, 4):
+        r = Renderer((W, H), (0, 1, 0), seed=21, texture_source="synthetic", texture_size=(2048, 1024))
+        r.set_kernel_variant(variant)
+        r.accumulate(8)
+        r.accumulate(5)
+        out[variant] = r.fetch_hdr()
+    assert bits_equal_fraction(out[2], out[4]) == 1.0
+    assert out[4].max() > 0
