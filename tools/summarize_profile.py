@@ -2,7 +2,7 @@
 """Condense a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md + profiles/hbm_traffic.json.
 
 A frame of the bench workload is one de_accumulate(64) call.  With kernel variant 2 that is one render_kernel_v2 launch; with the
-default variant 4 it is a sequence: two batches side by side, each = the wavefront pipeline's stage kernels for two vertex rounds
+default variant 4 it is a sequence: two batches side by side, each = the wavefront pipeline's stage kernels for the first vertex rounds
 (v3_*) + render_kernel_v2 as finisher.  Counters are therefore summed over ALL render kernels of a run and divided by its number
 of frames; the frame duration is the busy span of the render kernels in the kernel trace."""
 import csv, glob, json, os, re, sys
