@@ -242,6 +242,7 @@ struct de_ctx {
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
     size_t v3_max_items = (size_t)1 << 27;   // paths per batch (512 B each: 68 GB per pipe at 2^27 = a whole 1920x1080x64-spp frame; v3_reserve asks the device first and the batch shrinks when there is no room); env DE_V3_MAX_ITEMS
     size_t v3_test_budget = 0;       // env DE_V3_TEST_BUDGET (paths): see v3_reserve
+    int v3_slack_wpc = 14;           // the largest wave budget any stage grid may get (set after the env knobs are read): sizes the queues' room for holes
     int v3_wpc = 14;                 // waves per CU the v3 grids are sized for (env DE_V3_WPC; per class: DE_V3_WPC_ST / _GAS / _CLOUD / _FLAT).
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
                                      // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
@@ -423,7 +424,7 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     if (P.cold) hipFree(P.cold);
     P.cold = nullptr; P.capacity = 0;
     // room for every path plus the holes the waves' last bulk reservations leave (render_kernel_v3.hip: push / close_out)
-    const size_t slack = 4u * (size_t)c->n_cus * 32u * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
+    const size_t slack = 4u * (size_t)c->n_cus * (size_t)c->v3_slack_wpc * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
     // 512 B per path: ask first — other contexts, the host framework and the next pipe want memory too (8 GB stay free)
     size_t free_b = 0, total_b = 0;
     const size_t need_b = (size_t)wf::NQ * (n_items + slack) * sizeof(wf::Rec) + n_items * sizeof(wf::Cold);
@@ -464,12 +465,12 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
     A.a = a;
     A.cold = P.cold;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
-    A.capacity = (uint32_t)(P.capacity + 4u * (size_t)c->n_cus * 32u * DE_V3_BULK);
+    A.capacity = (uint32_t)(P.capacity + 4u * (size_t)c->n_cus * (size_t)c->v3_slack_wpc * DE_V3_BULK);
     const unsigned by_work = (unsigned)((A.n_items + DE_V3_BLOCK - 1) / DE_V3_BLOCK);
     dim3 block(DE_V3_BLOCK), grid(1);
     auto size_grid = [&](int cls) {
         unsigned wpc = (unsigned)(c->v3_wpc_class[cls] > 0 ? c->v3_wpc_class[cls] : c->launch_wpc);
-        if (wpc > 32u) wpc = 32u;                     // the queues' room for holes is sized for 32 waves per CU
+        if (wpc > (unsigned)c->v3_slack_wpc) wpc = (unsigned)c->v3_slack_wpc;      // the queues' room for holes is sized for that many waves per CU
         const unsigned machine = (unsigned)c->n_cus * wpc;
         grid = dim3(by_work < machine ? by_work : machine);
     };
@@ -695,6 +696,10 @@ int de_create(int device, int width, int height, de_ctx** out) {
         if (const char* e4 = getenv("DE_AUTO_MIN_ITEMS")) { long long x = atoll(e4); if (x >= 0) c->auto_min_items = (unsigned long long)x; }
         env_int("DE_V3_WPC_ST", &c->v3_wpc_class[0], 1); env_int("DE_V3_WPC_GAS", &c->v3_wpc_class[1], 1);
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
+        c->v3_slack_wpc = c->v3_wpc > c->auto_wpc ? c->v3_wpc : c->auto_wpc;
+        for (int i = 0; i < 4; ++i) if (c->v3_wpc_class[i] > c->v3_slack_wpc) c->v3_slack_wpc = c->v3_wpc_class[i];
+        if (c->v3_slack_wpc > 32) c->v3_slack_wpc = 32;
+        if (c->v3_slack_wpc < 1) c->v3_slack_wpc = 1;
     }
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
