@@ -259,10 +259,10 @@ struct de_ctx {
     // the state machine and its launch slots.
     int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
-    // views whose paths are long (limb views through thick cloud: 3.5 ns of GPU time per path against 1.6 for the default camera)
+    // views whose paths are long (limb views through thick cloud: 2.4 - 2.9 ns of GPU time per path against 1.0 - 1.4 for the default camera)
     // keep the stage kernels full for more rounds and amortise a third, smaller batch: the pipeline then runs auto_deep_depths
     // rounds on auto_deep_pipes pipes (env DE_AUTO_DEEP_NS in 1/100 ns per path / DE_AUTO_DEEP_DEPTHS / DE_AUTO_DEEP_PIPES)
-    int auto_deep_ns_x100 = 250, auto_deep_depths = 5, auto_deep_pipes = 3;
+    int auto_deep_ns_x100 = 200, auto_deep_depths = 5, auto_deep_pipes = 3;
     int last_v3_slot[4] = {-1, -1, -1, -1};  // a pipe's launches follow each other
     de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
     int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked

@@ -197,12 +197,9 @@ def test_pipeline_batches_shrink_when_the_queues_do_not_fit(Renderer, monkeypatc
 def test_default_variant_full_frame_equals_the_state_machine(Renderer, preset, monkeypatch):
     """BASELINE configs[1] as the bench runs it — 1920x1080 x 64 spp, quality-2 maps: two 32-spp batches side by side on two pipes,
     three pipeline rounds, the state machine as finisher — against the state machine alone, every pixel.  Twice: the second frame
-    is issued after the first has left its timestamps, which moves the sunset-hurricane view to five rounds on three pipes (its
-    isolated frames measure 2.4 ns per path, frames in flight 2.9: the threshold is lowered to 2.0 here so that the test takes the
-    deep setting either way)."""
+    is issued after the first has left its timestamps, which moves the sunset-hurricane view (2.4 ns per path against a threshold
+    of 2.0) to five rounds on three pipes."""
     import gc
-    if preset:
-        monkeypatch.setenv("DE_AUTO_DEEP_NS", "200")
     W, H, SPP = 1920, 1080, 64
     frames = {}
     for variant in (2, 4):
