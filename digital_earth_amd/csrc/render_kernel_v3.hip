@@ -127,14 +127,25 @@ DE_DEV bool next_chunk(uint32_t n, uint32_t* chunk, uint32_t* idx, bool* active)
 
 // ---- persistent lanes: the loop stages (ST, GAS, CLOUD).  A lane takes a record, runs the stage's loop on it one step per trip
 // of the wave loop, and when it ends keeps the finished record until the wave's next SERVICE: all finished records are pushed
-// (one atomic per target queue) and the idle lanes take new records.  A service runs when >= DE_V3_SERVICE lanes are idle
-// (or nothing is running), so its ~150 instructions are shared by a dozen records and no lane waits long: with one record per
-// lane and no refill, a wave would idle behind its longest record (cloud segments have a heavy tail: lane utilisation 0.1).
-#ifndef DE_V3_SERVICE
-#define DE_V3_SERVICE 12
+// (one atomic per target queue) and the idle lanes take new records.  A service runs when >= SERVICE lanes are idle (or nothing
+// is running), so its ~150 instructions and its wait for the new records' loads are shared by that many records: with one record
+// per lane and no refill, a wave would idle behind its longest record (cloud segments have a heavy tail: lane utilisation 0.1).
+// The threshold is per stage (A/B on three cameras, profiles/experiments/r3_variant4_sweeps.txt): cloud segments are long and uneven
+// — refill early (12); gas segments are short and a gas step is 60 instructions around one load — a service costs several steps,
+// so wait for most of the wave (48); the sphere trace sits between (32).
+#ifndef DE_V3_SVC_ST
+#define DE_V3_SVC_ST 32
 #endif
+#ifndef DE_V3_SVC_GAS
+#define DE_V3_SVC_GAS 48
+#endif
+#ifndef DE_V3_SVC_CLOUD
+#define DE_V3_SVC_CLOUD 12
+#endif
+#ifndef DE_V3_IN_CHUNK
 #define DE_V3_IN_CHUNK 256u
-template <typename Stage, int NT>
+#endif
+template <int SERVICE, typename Stage, int NT>
 DE_DEV void run_stage(const Args& A, const Queue& q, Stage& st, const int (&targets)[NT]) {
     const uint32_t n = min(q.ctl[0], A.capacity);
     const int lane = (int)(threadIdx.x & 63u);
@@ -150,7 +161,7 @@ DE_DEV void run_stage(const Args& A, const Queue& q, Stage& st, const int (&targ
     int target = -1;
     for (;;) {
         const unsigned long long m_busy = __ballot(busy);
-        if (m_busy == 0ull || (!exhausted && 64 - __popcll(m_busy) >= DE_V3_SERVICE)) {
+        if (m_busy == 0ull || (!exhausted && 64 - __popcll(m_busy) >= SERVICE)) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) push(A.q[targets[k]], out[k], p, fin && target == targets[k]);
             fin = false;
@@ -449,7 +460,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_st_kernel(wf::Args A, const Fr
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
     StStage<CLAMP> st{A.a, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
     const int targets[4] = {Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN};
-    run_stage(A, A.q[Q_ST], st, targets);
+    run_stage<DE_V3_SVC_ST>(A, A.q[Q_ST], st, targets);
 }
 
 // ------------------------------------------------------------------------------------------------ GAS: delta / ratio tracking
@@ -518,7 +529,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_gas_kernel(wf::Args A) {
     using namespace wf;
     GasStage st{A.a};
     const int targets[4] = {Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN};
-    run_stage(A, A.q[Q_GAS], st, targets);
+    run_stage<DE_V3_SVC_GAS>(A, A.q[Q_GAS], st, targets);
 }
 
 // ------------------------------------------------------------------------------------------------ CLOUD: tracking through the cloud shell
@@ -580,7 +591,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_cloud_kernel(wf::Args A) {
     using namespace wf;
     CloudStage<CLAMP> st{A.a};
     const int targets[3] = {Q_EVENT, Q_SCFIN, Q_SURFFIN};
-    run_stage(A, A.q[Q_CLOUD], st, targets);
+    run_stage<DE_V3_SVC_CLOUD>(A, A.q[Q_CLOUD], st, targets);
 }
 
 // ------------------------------------------------------------------------------------------------ EVENT: event resolution, light sample, branch
