@@ -247,16 +247,15 @@ struct de_ctx {
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
                                      // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
     int v3_wpc_class[4] = {0, 0, 0, 0};   // 0 = v3_wpc; index: 0 sphere trace (and primary), 1 gas, 2 cloud, 3 the straight-line stages
-    int hybrid_v3_spp = 0;           // experiment (env DE_HYBRID_V3): of each de_accumulate call with variant 2, this many samples per pixel run through the v3 pipeline on another launch slot, side by side with v2
     int launch_variant = 2;          // variant of the sub-launch being issued
     int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
     int launch_pipes = 1;            // pipes the call being issued runs side by side
     int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
-    // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3b_summary.md): two vertex rounds in the
-    // pipeline + the state machine as finisher beat the state machine alone by 4 % (default camera, 64 spp) to 47 % (limb view),
-    // with 8 waves per CU per pipe, two pipes for batches above 48 M paths and four below (small batches: more tails to overlap;
-    // large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay with
-    // the state machine and its launch slots.
+    // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3d_summary.md, profiles/experiments/): three vertex
+    // rounds in the pipeline + the state machine as finisher beat the state machine alone by 7 % (default camera, 64 spp) to 77 %
+    // (limb view), with 8 waves per CU per pipe, two pipes for batches above 48 M paths and four below (small batches: more tails to
+    // overlap; large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay
+    // with the state machine and its launch slots.
     int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
     // views whose paths are long (limb views through thick cloud: 2.4 - 2.9 ns of GPU time per path against 1.0 - 1.4 for the default camera)
@@ -682,7 +681,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_V2_G", &c->tune_gas, 0); env_int("DE_V2_CHUNK", &c->tune_chunk, 1); env_int("DE_V2_WPC", &c->tune_wpc, 1);
         env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
         if (const char* e3 = getenv("DE_V3_MAX_ITEMS")) { long long x = atoll(e3); if (x >= 4096) c->v3_max_items = (size_t)x; }
-        env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_HYBRID_V3", &c->hybrid_v3_spp, 0);
+        env_int("DE_V3_WPC", &c->v3_wpc, 1);
         env_int("DE_V3_PIPES", &c->v3_pipes, 1); if (c->v3_pipes > 4) c->v3_pipes = 4;
         env_int("DE_V3_BATCHES", &c->v3_batches, 1);
         env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;
@@ -961,7 +960,6 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
     const bool v2 = c->kernel_variant != 1 && !(c->p.flags & DE_FLAG_RAY_MARCHER);     // per-sample records + accumulate_kernel
-    const bool hybrid = c->kernel_variant == 2 && v2 && !c->count && c->hybrid_v3_spp > 0 && spp > c->hybrid_v3_spp;
     // does this call go through the wavefront pipeline, and with which settings
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
     bool pipeline = false, mid_call = false;
@@ -1026,7 +1024,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
                     call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
     const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
-    const bool v3k = (pipeline || hybrid) && v2 && !c->count;      // some sub-launch runs the v3 pipeline
+    const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
     // contribution buffer (kept <= 4 GB).  Larger requests are split here; the sample index continues from launch to launch
@@ -1044,7 +1042,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (cap > cap3) cap = cap3;
             // two pipes: a call is cut in (at least) two batches that run side by side
             const int nb = batches < spp ? batches : spp;
-            if (pipes >= 2 && !hybrid && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
+            if (pipes >= 2 && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
@@ -1057,21 +1055,19 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
     }
     bool first = true;
-    const int v2_part = hybrid ? spp - c->hybrid_v3_spp : (pipeline ? 0 : spp);     // samples [0, v2_part) by variant 1 / 2, the rest by v3
     for (int done = 0; done < spp && a.n_tiles > 0;) {
-        bool this_v3 = v3k && done >= v2_part;
-        const int part_end = (v3k && !this_v3) ? v2_part : spp;
-        int n = (part_end - done < max_spp) ? part_end - done : max_spp;
+        bool this_v3 = v3k;
+        int n = (spp - done < max_spp) ? spp - done : max_spp;
         // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
         // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
         // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
         // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
         const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
-        // render_kernel_v3 has ONE set of stage queues per context and no long tail to hide: its launches run one after the other
-        const int n_cycle_want = (v3k && !hybrid) ? pipes : ((need_bytes > ((size_t)96 << 20) || hybrid) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
+        // pipeline launches cycle through the call's pipes (one launch slot each)
+        const int n_cycle_want = v3k ? pipes : ((need_bytes > ((size_t)96 << 20)) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
         const int n_cycle = n_cycle_want < c->n_slots ? n_cycle_want : c->n_slots;      // never a slot the context stream does not join
         const int si = c->next_slot % n_cycle;
-        const int pipe = (v3k && !hybrid && pipes >= 2) ? si : 0;
+        const int pipe = (v3k && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle;
         if (this_v3) {
             // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),

@@ -11,5 +11,5 @@ ts = []
 for _ in range(3):
     r.reset_framebuffer(); r.synchronize()
     t0 = time.perf_counter(); r.accumulate(SPP); r.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-print("hybrid v3 spp %s, v3 wpc %s, v2 wpc %s: %s ms -> %.0f Msamples/s" % (os.environ.get("DE_HYBRID_V3", "0"), os.environ.get("DE_V3_WPC", "32"), sys.argv[1] if len(sys.argv) > 1 else "20", ["%.1f" % t for t in ts], W * H * SPP / min(ts) / 1e3))
-np.save("/tmp/hyb_%s.npy" % os.environ.get("DE_HYBRID_V3", "0"), r.fetch_hdr())
+knobs = " ".join("%s=%s" % kv for kv in sorted(os.environ.items()) if kv[0].startswith("DE_"))
+print("single frames, 1920x1080 x 64 spp [%s]: %s ms -> %.0f Msamples/s" % (knobs, ["%.1f" % t for t in ts], W * H * SPP / min(ts) / 1e3))
