@@ -255,9 +255,9 @@ def main():
         return time.perf_counter() - ta
 
     # every launch slot of every context allocates its record buffer at its first launch; a context whose calls are a SHARE of the
-    # frame (tile partition: 8 M .. 96 M paths per call) also times its first 16 such calls on both kernels before it settles on
+    # frame (tile partition: 8 M .. 96 M paths per call) also times its first 64 such calls on both kernels before it settles on
     # one (include/digital_earth.h, de_set_kernel_variant): let it settle before the timed region
-    n_prime = 18 if (world > 1 or args.simulate_world > 1) else 3
+    n_prime = 66 if (world > 1 or args.simulate_world > 1) else 3
     for f in frames:
         for _ in range(n_prime):
             step(f)

@@ -223,15 +223,18 @@ struct de_ctx {
     float auto_ratio = -1.f;         // last known (records queued for round 2) / (paths started); < 0 = none yet
     // Calls between auto_min_items and the two-pipe size (a rank's share of a tile partition, accumulate(16)): on light views the state
     // machine alone is 2-10 % faster, on heavier ones the pipeline (four pipes) 25-50 % — and no cheap statistic separates the two
-    // (profiles/experiments).  So the context measures: eight such calls on the state machine, eight on the pipeline; the time from
-    // the completion of the third to the completion of the eighth, per path, is what a caller sees of either kernel whatever its
-    // calling pattern (overlapping frames or one call at a time).  The faster one (the pipeline must win by 3 %: it costs memory)
-    // is kept for auto_mid_keep calls, then both are measured again.  Nothing is waited for: the decision is taken by the first call
-    // that finds the timestamps there.  env DE_AUTO_MID: 0 = as described, 1 = always the pipeline, 2 = never; DE_AUTO_MID_KEEP
+    // (profiles/experiments).  So the context measures: auto_mid_calls (32) such calls on the state machine, as many on the pipeline,
+    // and for each run the time between the completion of its 9th and of its last call, per path.  Completions are chained (the HDR
+    // sums keep call order), so calls that overlap finish in bunches and a window of a few completions covers anything from half to
+    // twice its calls' work; over 23 calls the error is a few per cent, and the first quarter of a run takes the allocations and the
+    // start-up of the slots.  The faster kernel (the pipeline must win by 3 %: it costs memory) is kept for auto_mid_keep calls, then
+    // both are measured again.  Nothing is waited for: the decision is taken by the first call that finds the timestamps there.
+    // env DE_AUTO_MID: 0 = as described, 1 = always the pipeline, 2 = never; DE_AUTO_MID_CALLS, DE_AUTO_MID_KEEP
+    int auto_mid_calls = 32;
     int auto_mid_mode = 0, auto_mid_keep = 1024;
     bool auto_mid_pipeline = false;
-    hipEvent_t mid_a[2] = {nullptr, nullptr}, mid_b[2] = {nullptr, nullptr};   // completion of call 3 / call 8 of a measuring phase
-    unsigned long long mid_items[2] = {0, 0};      // paths of calls 4..8
+    hipEvent_t mid_a[2] = {nullptr, nullptr}, mid_b[2] = {nullptr, nullptr};   // completion of the 9th / of the last call of a measuring run
+    unsigned long long mid_items[2] = {0, 0};      // paths of the calls between them
     bool mid_b_recorded[2] = {false, false};
     int mid_phase = 0, mid_calls = 0;        // 0: measuring the state machine, 1: measuring the pipeline, 2: decided
     float mid_ns[2] = {-1.f, -1.f};          // last measurement, ns per path: [0] state machine, [1] pipeline
@@ -689,6 +692,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
         env_int("DE_AUTO_MID", &c->auto_mid_mode, 0); env_int("DE_AUTO_MID_KEEP", &c->auto_mid_keep, 1);
+        env_int("DE_AUTO_MID_CALLS", &c->auto_mid_calls, 8);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -986,14 +990,15 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (c->auto_mid_mode == 1) c->auto_mid_pipeline = true;
             else if (c->auto_mid_mode == 2) c->auto_mid_pipeline = false;
             else {
-                if (c->mid_phase == 0 && c->mid_calls >= 8) { c->mid_phase = 1; c->mid_calls = 0; }
-                else if (c->mid_phase == 1 && c->mid_calls >= 8 && c->mid_b_recorded[0] && c->mid_b_recorded[1] && hipEventQuery(c->mid_b[1]) == hipSuccess) {
+                if (c->mid_phase == 0 && c->mid_calls >= c->auto_mid_calls) { c->mid_phase = 1; c->mid_calls = 0; }
+                else if (c->mid_phase == 1 && c->mid_calls >= c->auto_mid_calls && c->mid_b_recorded[0] && c->mid_b_recorded[1] && hipEventQuery(c->mid_b[1]) == hipSuccess) {
                     float t0 = 0.f, t1 = 0.f;
                     if (hipEventElapsedTime(&t0, c->mid_a[0], c->mid_b[0]) == hipSuccess && hipEventElapsedTime(&t1, c->mid_a[1], c->mid_b[1]) == hipSuccess
                         && c->mid_items[0] && c->mid_items[1]) {
                         c->mid_ns[0] = t0 * 1e6f / (float)c->mid_items[0];
                         c->mid_ns[1] = t1 * 1e6f / (float)c->mid_items[1];
                         c->auto_mid_pipeline = c->mid_ns[1] < 0.97f * c->mid_ns[0];
+                        if (getenv("DE_AUTO_TRACE")) fprintf(stderr, "[de] mid-size measurement: state machine %.2f ms for %llu paths, pipeline %.2f ms for %llu paths\n", t0, c->mid_items[0], t1, c->mid_items[1]);
                     } else c->auto_mid_pipeline = false;
                     c->mid_phase = 2; c->mid_calls = 0;
                 } else if (c->mid_phase == 2 && c->mid_calls >= c->auto_mid_keep) {
@@ -1132,9 +1137,10 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true;
             if (mid_call && mid_idx >= 0 && c->mid_phase < 2) {
                 const int m = c->mid_phase;
-                if (mid_idx == 2) HIP_TRY(hipEventRecord(c->mid_a[m], s.stream));
-                if (mid_idx >= 3 && mid_idx <= 7) c->mid_items[m] += call_items;
-                if (mid_idx == 7) { HIP_TRY(hipEventRecord(c->mid_b[m], s.stream)); c->mid_b_recorded[m] = true; }
+                const int L = c->auto_mid_calls;
+                if (mid_idx == L / 4) HIP_TRY(hipEventRecord(c->mid_a[m], s.stream));
+                if (mid_idx > L / 4 && mid_idx < L) c->mid_items[m] += call_items;
+                if (mid_idx == L - 1) { HIP_TRY(hipEventRecord(c->mid_b[m], s.stream)); c->mid_b_recorded[m] = true; }
             }
         }
     }

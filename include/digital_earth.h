@@ -210,7 +210,7 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *                batches side by side) and the surviving paths finish in the state machine (variant 2).  Large = more than 96 M
  *                paths: always (two batches; views with long paths — GPU time per path of EARLIER calls, read without waiting —
  *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the context times
- *                eight calls on either kernel and keeps the faster one for 1024 calls.  Smaller calls run variant 2 alone,
+ *                a run of 32 calls on either kernel and keeps the faster one for 1024 calls.  Smaller calls run variant 2 alone,
  *                overlapping through the launch slots.  The choices move time, never bits
  *   2            wave-level state machine only (render_kernel_v2.hip)
  *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS

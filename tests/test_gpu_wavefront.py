@@ -154,12 +154,13 @@ def test_automatic_variant_changes_its_settings_between_calls(Renderer, monkeypa
 
 
 def test_automatic_variant_moves_mid_size_calls_between_the_kernels(Renderer, monkeypatch):
-    """Calls between 8 M paths and the two-pipe size are measured on both kernels — eight calls on the state machine, eight on the
-    pipeline (four pipes), the faster one kept (here for two calls only, then measured again).  Whatever the timestamps say, the
-    frame has the bits of the state machine alone."""
+    """Calls between 8 M paths and the two-pipe size are measured on both kernels — a run of calls on the state machine, a run on the
+    pipeline (four pipes; here eight calls each instead of 32), the faster one kept (here for two calls only, then measured
+    again).  Whatever the timestamps say, the frame has the bits of the state machine alone."""
     W, H = 128, 64
     monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
     monkeypatch.setenv("DE_AUTO_MID_KEEP", "2")
+    monkeypatch.setenv("DE_AUTO_MID_CALLS", "8")
     out = {}
     for variant in (2, 4):
         r = Renderer((W, H), (0, 1, 0), seed=9, texture_source="synthetic", texture_size=(2048, 1024))
