@@ -203,6 +203,7 @@ struct de_ctx {
     bool reduce_timing_valid = false;
     void* comm = nullptr;        // the context's own RCCL communicator (de_comm_init)
     int comm_rank = 0, comm_world = 1;
+    bool trace = false;          // env DE_AUTO_TRACE, read once in de_create: print what the launch policy measured and chose
     int kernel_variant = 4;      // 4 = automatic (default): large launches run the first vertex rounds in the wavefront pipeline and finish in the state machine, small ones run the state machine alone; 1 = per-lane loops (render_kernel.hip), 2 = wave-level state machine (render_kernel_v2.hip), 3 = wavefront pipeline through HBM queues (render_kernel_v3.hip)
     // render_kernel_v3: one "pipe" = a set of stage queues + cold records.  Two pipes let two batches of paths run side by side on
     // two launch slots, so that the tail-heavy small launches of one overlap the large launches of the other (env DE_V3_PIPES)
@@ -611,6 +612,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, struct UniqueId128, int) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;   // optional: which rank of an external communicator this context is
     const char* (*GetErrorString)(int) = nullptr;
 };
 struct UniqueId128 { char internal[128]; };        // ncclUniqueId (rccl.h:43), passed BY VALUE to ncclCommInitRank
@@ -641,6 +643,7 @@ int load_rccl() {
     r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(h, "ncclReduce");
     r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    r.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy || !r.GetErrorString)
         return fail(DE_ERR_STATE, "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy / ncclGetErrorString");
     g_rccl = r;
@@ -676,6 +679,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     de_ctx* c = new de_ctx();
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
+    c->trace = getenv("DE_AUTO_TRACE") != nullptr;
     if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '4') c->kernel_variant = kv[0] - '0'; }
     c->launch_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
     {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
@@ -998,7 +1002,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
                         c->mid_ns[0] = t0 * 1e6f / (float)c->mid_items[0];
                         c->mid_ns[1] = t1 * 1e6f / (float)c->mid_items[1];
                         c->auto_mid_pipeline = c->mid_ns[1] < 0.97f * c->mid_ns[0];
-                        if (getenv("DE_AUTO_TRACE")) fprintf(stderr, "[de] mid-size measurement: state machine %.2f ms for %llu paths, pipeline %.2f ms for %llu paths\n", t0, c->mid_items[0], t1, c->mid_items[1]);
+                        if (c->trace) fprintf(stderr, "[de] mid-size measurement: state machine %.2f ms for %llu paths, pipeline %.2f ms for %llu paths\n", t0, c->mid_items[0], t1, c->mid_items[1]);
                     } else c->auto_mid_pipeline = false;
                     c->mid_phase = 2; c->mid_calls = 0;
                 } else if (c->mid_phase == 2 && c->mid_calls >= c->auto_mid_keep) {
@@ -1024,7 +1028,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
                 if (c->auto_pipes <= 0 && c->auto_deep_pipes >= 2) { pipes = c->auto_deep_pipes; if (batches < pipes) batches = pipes; }
             }
         }
-        if (getenv("DE_AUTO_TRACE"))
+        if (c->trace)
             fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d batches %d\n",
                     call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
@@ -1085,7 +1089,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (rc3 == V3_NO_MEMORY) { this_v3 = false; rc3 = DE_OK; }
             if (rc3) return rc3;
         }
-        c->launch_variant = this_v3 ? 3 : base_variant;
+        // a batch whose queues do not fit runs on the state machine — also under kernel variant 3: its pipe has just been freed
+        c->launch_variant = this_v3 ? 3 : (base_variant == 3 ? 2 : base_variant);
         LaunchSlot& s = c->slot[si];
         if (v2) {
             const size_t need = (size_t)a.n_tiles * 64u * (size_t)n;
@@ -1335,7 +1340,10 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     float* recv = c->d_hdr;
     if (progressive) {
         // out of place: every rank keeps accumulating into its own buffer; the root receives the assembled frame elsewhere
-        if (!c->d_assembled) HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
+        if (!c->d_assembled) {
+            HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->d_assembled, 0, count * sizeof(float), c->stream));      // non-root ranks: scratch, but never uninitialised
+        }
         recv = c->d_assembled;
     } else {
         touched_hdr(c);
@@ -1348,7 +1356,11 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     c->reduce_timing_valid = true;
     if (progressive) {
         touched_hdr(c);                        // the collective READS d_hdr: the next accumulate_kernel is ordered after it
-        c->display_src = c->d_assembled;
+        // only the root receives the assembled frame: elsewhere ncclReduce leaves recvbuff alone, and the display / fetch entry
+        // points keep reading the rank's own sums
+        int my_rank = c->comm_rank;
+        if (comm) { if (!g_rccl.CommUserRank || g_rccl.CommUserRank(use, &my_rank) != 0) my_rank = -1; }
+        if (my_rank == root) c->display_src = c->d_assembled;
     }
     return DE_OK;
 }

@@ -94,8 +94,9 @@ class DistributedFrame:
         renderer.set_tile_partition(rank, world)
 
     def _reduce(self, out=None):
-        if self.world > 1:
-            self.r.flush()                    # the collective is torch's own work on this stream: order it after the launches
+        # what follows is torch's own work on this stream (the collective, or with one rank the copy into `out`): order it
+        # after the launches — they run on the context's launch slots, not on this stream
+        self.r.flush()
         self._ev[0].record(self.stream)
         reduce_hdr(self.hdr, dst=0, out=out)
         self._ev[1].record(self.stream)

@@ -90,6 +90,21 @@ def test_progressive_frames_on_two_ranks(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_progressive_frames_on_one_rank(tmp_path):
+    """with ONE rank the out-of-place reduce is a copy on the torch stream; it must be ordered after the launch slots
+    (`DistributedFrame._reduce` flushes unconditionally), or the assembled frame that gets displayed and dumped is a partial sum."""
+    plain, prog = str(tmp_path / "plain.npy"), str(tmp_path / "prog.npy")
+    common = [a if a != "3" else "6" for a in COMMON]
+    p1 = _run([sys.executable, "bench.py", "--gpus", "1", "--dump-hdr", plain] + common)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    p2 = _run([sys.executable, "bench.py", "--gpus", "1", "--progressive", "2", "--dump-hdr", prog] + common)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    a, b = np.load(plain), np.load(prog)
+    assert a.max() > 0 and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_library_communicator_refuses_two_ranks_on_one_gpu_cleanly():
     """`bench.py --reduce lib` (de_comm_init / de_reduce inside the library) with two ranks on ONE device: RCCL refuses a

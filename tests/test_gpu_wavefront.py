@@ -184,13 +184,14 @@ def test_pipeline_batches_shrink_when_the_queues_do_not_fit(Renderer, monkeypatc
     monkeypatch.setenv("DE_AUTO_MID", "1")
     monkeypatch.setenv("DE_V3_TEST_BUDGET", str(budget))
     out = {}
-    for variant in (2, 4):
+    for variant in (2, 4, 3):      # 3: the pipeline alone must fall back to the state machine as well (it launched on freed queues)
         r = Renderer((W, H), (0, 1, 0), seed=21, texture_source="synthetic", texture_size=(2048, 1024))
         r.set_kernel_variant(variant)
         r.accumulate(8)
         r.accumulate(5)
         out[variant] = r.fetch_hdr()
     assert bits_equal_fraction(out[2], out[4]) == 1.0
+    assert bits_equal_fraction(out[2], out[3]) == 1.0
     assert out[4].max() > 0
 
 
