@@ -15,6 +15,7 @@
 #include "render_kernel.hip"
 #include "render_kernel_v2.hip"
 #include "render_kernel_v3.hip"
+#include "render_kernel_v5.hip"
 #include "aux_kernels.hip"
 
 namespace {
@@ -251,8 +252,29 @@ struct de_ctx {
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
                                      // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
     int v3_wpc_class[4] = {0, 0, 0, 0};   // 0 = v3_wpc; index: 0 sphere trace (and primary), 1 gas, 2 cloud, 3 the straight-line stages
+    // render_kernel_v5 (kernel variant 5): one persistent stage-scheduler launch per call.  Each launch slot that runs it owns a chunk
+    // pool, the queue rings, the control words and the cold records of its launch (launches of different slots overlap).
+    struct V5State {
+        uint4* pool = nullptr;
+        uint32_t* ctl = nullptr;
+        uint32_t* rings = nullptr;
+        uint32_t* free_ring = nullptr;
+        unsigned long long* cold = nullptr;
+        RenderArgs* d_args = nullptr;     // the launch's RenderArgs (written by v5_init_kernel)
+        uint32_t* h_status = nullptr;     // pinned, device-visible: the kernel's abort code
+        size_t cold_items = 0;
+        uint32_t pool_chunks = 0, ring_cells = 0, n_shards = 0;
+    } v5s[DE_MAX_SLOTS];
+    int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
+    int v5_shards = 1;               // queue sets (1, or 8 = one per XCD; env DE_V5_SHARDS)
+    int v5_pool_log2 = 18;           // chunks of 64 records in a slot's pool (2^18 = 1 GB; env DE_V5_POOL_LOG2)
+    int v5_claim_k = 2, v5_age = 20000, v5_closers_per_cu = 2, v5_stats = 0;   // env DE_V5_CLAIM_K / _AGE (10 ns ticks) / _CLOSERS / _STATS
+    int v5_reserve_pct = 25;         // new paths start only while this share of the pool is free (env DE_V5_RESERVE_PCT)
+    size_t v5_max_items = (size_t)1 << 27;   // paths per launch (64 B of cold record each; env DE_V5_MAX_ITEMS)
+    int v5_batches = 1;              // launches a large call is cut into (they overlap on the launch slots; env DE_V5_BATCHES)
     int launch_variant = 2;          // variant of the sub-launch being issued
     int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
+    int launch_slot = 0;             // launch slot of the sub-launch being issued
     int launch_pipes = 1;            // pipes the call being issued runs side by side
     int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
     // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3d_summary.md, profiles/experiments/): three vertex
@@ -287,12 +309,13 @@ int join_slots(de_ctx* c) {
 // context-stream work that the next launches must be ordered after: what a render kernel reads / the HDR buffer
 void touched_render_inputs(de_ctx* c) { c->gen_render++; }
 void touched_hdr(de_ctx* c) { c->gen_hdr++; }
+int check_v5_status(de_ctx* c);
 int sync_all(de_ctx* c) {
     for (int i = 0; i < c->n_slots; ++i)
         if (c->slot[i].stream) HIP_TRY(hipStreamSynchronize(c->slot[i].stream));
     for (int i = 0; i < c->n_slots; ++i) c->slot[i].pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return DE_OK;
+    return check_v5_status(c);
 }
 void release_loan(de_ctx* c) {
     if (c->lender) { c->lender->loans--; c->lender = nullptr; }
@@ -537,6 +560,79 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
     return hipGetLastError();
 }
 
+// render_kernel_v5: buffers of one launch slot.  Pool, rings and control words are sized once; the cold records grow with the
+// largest launch the slot has seen.
+int v5_reserve(de_ctx* c, int si, size_t n_items) {
+    de_ctx::V5State& S = c->v5s[si];
+    const uint32_t pool_chunks = 1u << c->v5_pool_log2;
+    if (!S.pool || S.pool_chunks != pool_chunks || S.n_shards != (uint32_t)c->v5_shards) {
+        HIP_TRY(hipStreamSynchronize(c->slot[si].stream));
+        if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
+        S.pool = nullptr; S.ctl = nullptr; S.rings = nullptr; S.free_ring = nullptr;
+        S.pool_chunks = pool_chunks; S.ring_cells = pool_chunks; S.n_shards = (uint32_t)c->v5_shards;
+        HIP_TRY(hipMalloc(&S.pool, (size_t)pool_chunks * DE_V5_CH * 64u));
+        HIP_TRY(hipMalloc(&S.ctl, (size_t)ps::C_WORDS * DE_V5_CTL_STRIDE * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&S.rings, (size_t)S.n_shards * wf::NQ * S.ring_cells * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&S.free_ring, (size_t)pool_chunks * sizeof(uint32_t)));
+        if (!S.d_args) HIP_TRY(hipMalloc(&S.d_args, sizeof(RenderArgs)));
+        if (!S.h_status) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.h_status), 64, hipHostMallocMapped));
+            S.h_status[0] = 0u;
+        }
+    }
+    if (n_items > S.cold_items) {
+        HIP_TRY(hipStreamSynchronize(c->slot[si].stream));
+        if (S.cold) hipFree(S.cold);
+        S.cold = nullptr; S.cold_items = 0;
+        if (hipMalloc(&S.cold, n_items * 64u) != hipSuccess) { (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no room for the cold records of a render_kernel_v5 launch (64 B per path): lower DE_V5_MAX_ITEMS"); }
+        S.cold_items = n_items;
+    }
+    return DE_OK;
+}
+hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si) {
+    de_ctx::V5State& S = c->v5s[si];
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    ps::Args A;
+    A.ra = S.d_args;
+    A.pool = S.pool; A.ctl = S.ctl; A.rings = S.rings; A.free_ring = S.free_ring; A.cold = S.cold;
+    uint32_t* d_status = nullptr;
+    hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_status), S.h_status, 0);
+    if (e != hipSuccess) return e;
+    A.status = d_status;
+    A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
+    A.pool_chunks = S.pool_chunks; A.ring_mask = S.ring_cells - 1u; A.n_shards = S.n_shards;
+    A.reserve_chunks = (uint32_t)((unsigned long long)S.pool_chunks * (unsigned)c->v5_reserve_pct / 100ull);
+    A.claim_k = (uint32_t)c->v5_claim_k; A.age_max = (uint32_t)c->v5_age;
+    A.closers = (uint32_t)(c->n_cus * c->v5_closers_per_cu);
+    A.idle_limit = 1u << 20;
+    // every launch starts from all-EMPTY rings, zeroed control words and a full free ring (a launch that ended on its abort word
+    // leaves them in any state)
+    e = hipMemsetAsync(S.rings, 0xff, (size_t)S.n_shards * wf::NQ * S.ring_cells * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v5_init_kernel, dim3((S.pool_chunks + 255u) / 256u), dim3(256), 0, stream, S.ctl, S.free_ring, S.pool_chunks, a, S.d_args);
+    const unsigned by_work = (unsigned)((A.n_items + 63u) / 64u);
+    const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v5_wpc;
+    dim3 grid(by_work < machine ? (by_work ? by_work : 1u) : machine), block(64);
+    if (c->v5_stats) {
+        if (clamp) hipLaunchKernelGGL((v5_kernel<true, true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, true>), grid, block, 0, stream, A, a.fc);
+    } else {
+        if (clamp) hipLaunchKernelGGL((v5_kernel<true, false>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, false>), grid, block, 0, stream, A, a.fc);
+    }
+    return hipGetLastError();
+}
+// after the host has synchronised: did a persistent launch leave on its abort word?
+int check_v5_status(de_ctx* c) {
+    for (int i = 0; i < DE_MAX_SLOTS; ++i) {
+        de_ctx::V5State& S = c->v5s[i];
+        if (S.h_status && S.h_status[0] != 0u) {
+            const uint32_t code = S.h_status[0];
+            S.h_status[0] = 0u;
+            return fail(DE_ERR_HIP, std::string("render_kernel_v5 left on its abort word (") + (code == ps::ERR_CELL_TIMEOUT ? "a ring cell was never stored" : code == ps::ERR_POOL_EMPTY ? "the chunk pool ran empty: raise DE_V5_POOL_LOG2" : "idle watchdog: work was lost") + "): the frame is invalid");
+        }
+    }
+    return DE_OK;
+}
+
 // One launch on `stream`.  v2 (the default path tracer): render_kernel_v2 writes the per-sample records, then — after `pre_acc`
 // has made the stream wait for the previous launch's accumulate_kernel and for context-stream work on the HDR buffer — accumulate_kernel
 // adds them to the HDR buffer.  The other kernels read-modify-write the HDR buffer themselves: `pre_acc` runs before them.
@@ -545,6 +641,14 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a, hipStream_t stream, Pre
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     const bool march = (c->p.flags & DE_FLAG_RAY_MARCHER) != 0;
     dim3 grid((unsigned)((a.n_tiles + 3) / 4)), block(256);
+    if (!march && c->launch_variant == 5 && MODE == 0) {
+        hipError_t e5 = launch_v5(c, a, stream, c->launch_slot);
+        if (e5 != hipSuccess) return e5;
+        hipError_t pe = pre_acc();
+        if (pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     if (!march && c->launch_variant == 3 && MODE == 0) {
         hipError_t e3 = launch_v3(c, a, stream, c->launch_pipe);
         if (e3 != hipSuccess) return e3;
@@ -599,7 +703,7 @@ int copy_out(de_ctx* c, float* out, const float* d_src) {
         HIP_TRY(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    return DE_OK;
+    return check_v5_status(c);
 }
 
 
@@ -680,8 +784,8 @@ int de_create(int device, int width, int height, de_ctx** out) {
     c->device = device; c->W = width; c->H = height;
     default_params(&c->p);
     c->trace = getenv("DE_AUTO_TRACE") != nullptr;
-    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '4') c->kernel_variant = kv[0] - '0'; }
-    c->launch_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
+    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '5') c->kernel_variant = kv[0] - '0'; }
+    c->launch_variant = (c->kernel_variant == 4 || c->kernel_variant == 5) ? 2 : c->kernel_variant;
     {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
         auto env_int = [](const char* name, int* v, int lo) { if (const char* e = getenv(name)) { int x = atoi(e); if (x >= lo) *v = x; } };
         env_int("DE_V2_THR", &c->tune_pend, 0); env_int("DE_V2_A", &c->tune_heavy, 0); env_int("DE_V2_B", &c->tune_b, 0);
@@ -703,6 +807,14 @@ int de_create(int device, int width, int height, de_ctx** out) {
         if (const char* e4 = getenv("DE_AUTO_MIN_ITEMS")) { long long x = atoll(e4); if (x >= 0) c->auto_min_items = (unsigned long long)x; }
         env_int("DE_V3_WPC_ST", &c->v3_wpc_class[0], 1); env_int("DE_V3_WPC_GAS", &c->v3_wpc_class[1], 1);
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
+        env_int("DE_V5_WPC", &c->v5_wpc, 1); env_int("DE_V5_SHARDS", &c->v5_shards, 1); env_int("DE_V5_POOL_LOG2", &c->v5_pool_log2, 10);
+        env_int("DE_V5_CLAIM_K", &c->v5_claim_k, 1); env_int("DE_V5_AGE", &c->v5_age, 1); env_int("DE_V5_CLOSERS", &c->v5_closers_per_cu, 1);
+        env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
+        if (const char* e7 = getenv("DE_V5_MAX_ITEMS")) { long long x = atoll(e7); if (x >= 4096) c->v5_max_items = (size_t)x; }
+        if (c->v5_shards != 8) c->v5_shards = c->v5_shards > 8 ? 8 : c->v5_shards;
+        if (c->v5_pool_log2 > 19) c->v5_pool_log2 = 19;      // 2^19 chunks x 4 KB = 2 GB: the buffer descriptor addresses < 4 GB
+        if (c->v5_claim_k > 4) c->v5_claim_k = 4;
+        if (c->v5_wpc > 32) c->v5_wpc = 32;
         c->v3_slack_wpc = c->v3_wpc > c->auto_wpc ? c->v3_wpc : c->auto_wpc;
         for (int i = 0; i < 4; ++i) if (c->v3_wpc_class[i] > c->v3_slack_wpc) c->v3_slack_wpc = c->v3_wpc_class[i];
         if (c->v3_slack_wpc > 32) c->v3_slack_wpc = 32;
@@ -778,6 +890,12 @@ int de_destroy(de_ctx* c) {
         if (P.h_round2) hipHostFree(P.h_round2);
         if (P.stat_ev) hipEventDestroy(P.stat_ev);
         for (int i = 0; i < 3; ++i) if (P.ev_t[i]) hipEventDestroy(P.ev_t[i]);
+    }
+    for (auto& S : c->v5s) {
+        if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
+        if (S.cold) hipFree(S.cold);
+        if (S.d_args) hipFree(S.d_args);
+        if (S.h_status) hipHostFree(S.h_status);
     }
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
         LaunchSlot& s = c->slot[i];
@@ -1032,7 +1150,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d batches %d\n",
                     call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
-    const int base_variant = c->kernel_variant == 4 ? 2 : c->kernel_variant;
+    const bool v5k = c->kernel_variant == 5 && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
+    const int base_variant = c->kernel_variant == 4 ? 2 : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
@@ -1052,6 +1171,13 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             // two pipes: a call is cut in (at least) two batches that run side by side
             const int nb = batches < spp ? batches : spp;
             if (pipes >= 2 && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
+        }
+        if (v5k) {   // 64 B of cold record per path of a launch
+            unsigned long long cap5 = (unsigned long long)c->v5_max_items / (nt * 64ull);
+            if (cap5 < 1) cap5 = 1;
+            if (cap > cap5) cap = cap5;
+            const int nb = c->v5_batches < spp ? c->v5_batches : spp;
+            if (nb >= 2 && call_items >= c->auto_min_items && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
@@ -1077,7 +1203,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         const int n_cycle = n_cycle_want < c->n_slots ? n_cycle_want : c->n_slots;      // never a slot the context stream does not join
         const int si = c->next_slot % n_cycle;
         const int pipe = (v3k && pipes >= 2) ? si : 0;
-        c->launch_pipe = pipe; c->launch_pipes = n_cycle;
+        c->launch_pipe = pipe; c->launch_pipes = n_cycle; c->launch_slot = si;
+        if (v5k) { int rc5 = v5_reserve(c, si, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
         if (this_v3) {
             // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),
             // and a batch of one sample per pixel that still does not fit runs on the state machine
@@ -1275,8 +1402,8 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
     return DE_OK;
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
-    if (!c || variant < 1 || variant > 4) return fail(DE_ERR_INVALID, "kernel variant must be 1, 2, 3 or 4");
-    c->kernel_variant = variant; c->launch_variant = variant == 4 ? 2 : variant;
+    if (!c || variant < 1 || variant > 5) return fail(DE_ERR_INVALID, "kernel variant must be 1 ... 5");
+    c->kernel_variant = variant; c->launch_variant = (variant == 4 || variant == 5) ? 2 : variant;
     return DE_OK;
 }
 int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }
@@ -1400,6 +1527,22 @@ int de_set_launch_slots(de_ctx* c, int n_slots, int n_big) {
 int de_set_wave_budget(de_ctx* c, int waves_per_cu) {
     if (!c || waves_per_cu < 1 || waves_per_cu > 20) return fail(DE_ERR_INVALID, "waves per CU must be 1..20");
     c->tune_wpc = waves_per_cu;
+    return DE_OK;
+}
+
+/* statistics block of the persistent stage scheduler (DE_V5_STATS=1), summed over the launch slots' LAST launches: out[k] = word k of
+ * render_kernel_v5.hip's ST_* list */
+int de_debug_v5_stats(de_ctx* c, uint64_t* out, int n) {
+    if (!c || !out || n < 0) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int k = 0; k < n; ++k) out[k] = 0;
+    std::vector<uint32_t> h((size_t)ps::C_WORDS * DE_V5_CTL_STRIDE);
+    for (auto& S : c->v5s) {
+        if (!S.ctl) continue;
+        HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < n && k < ps::ST_N; ++k) out[k] += h[(size_t)(ps::C_STAT0 + k) * DE_V5_CTL_STRIDE];
+    }
     return DE_OK;
 }
 

@@ -349,6 +349,243 @@ DE_DEV void write_contrib(const RenderArgs& a, uint32_t pid, float Ls, int node)
     a.contrib[pid] = make_uint2(asu(Ls), (uint32_t)node);
 }
 
+
+// renderer.py:305-314 + the head of the primary ray: work item w -> (pixel, sample) exactly as render_kernel_v2 maps them, the
+// path's generator, wavelength node (lib/colour.py:21-39; the first six tree levels from the wave's LDS copy) and camera ray
+DE_DEV void new_path(const RenderArgs& a, const FrameConsts& fc, const float* s_node_val, uint32_t w, Path& p) {
+    const uint32_t wq = w >> 6;
+    const uint32_t tile_k = (uint32_t)(((unsigned long long)wq * a.spp_magic) >> 40);
+    const uint32_t tile = a.tiles_identity ? tile_k : a.tiles[tile_k];
+    const int s_idx = (int)(wq - tile_k * (uint32_t)a.spp_count);
+    const int sub = (int)(w & 63u);
+    const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
+    const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
+    const uint32_t pixel = (uint32_t)(v * a.W + u);
+    rng_seed(p.rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
+    int node = 0;
+    if (!a.fixed_wavelength) {
+        const float sample = rng_next(p.rng);
+        node = 1;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const float val = (it < 6) ? s_node_val[node] : a.node_val[node];
+            if (val < sample) node = 2 * node + 1;
+            else if (val > sample) node = 2 * node;
+            else break;
+        }
+    }
+    p.pid = w;
+    p.W = v2::get_cast_dir(p.rng, fc, a.H, u, v);
+    p.P = fc.cam_pos;
+    p.meta = m_make(0, node, 0, 0, 0, 0);
+    p.x[5] = 0.0f;
+    ray_head(p);
+}
+
+// ---- access to the cold records.  The stage bodies below are written once and shared by this file's level-synchronous kernels and
+// by the persistent scheduler kernel (render_kernel_v5.hip); what differs is HOW a cold record travels between the workgroups that
+// touch it: here a kernel boundary lies between any two of them and plain loads / stores do; there the accessor writes through.
+struct ColdPlain {
+    Cold* base;
+    DE_DEV void get_thr_ls(uint32_t pid, float& thr, float& Ls) const { thr = base[pid].thr; Ls = base[pid].Ls; }
+    DE_DEV float get_ls(uint32_t pid) const { return base[pid].Ls; }
+    DE_DEV void set_thr_ls(uint32_t pid, float thr, float Ls) const { base[pid].thr = thr; base[pid].Ls = Ls; }
+    DE_DEV vec3 get_dir(uint32_t pid) const { return v3(base[pid].dx, base[pid].dy, base[pid].dz); }
+    DE_DEV void set_dir(uint32_t pid, vec3 D) const { base[pid].dx = D.x; base[pid].dy = D.y; base[pid].dz = D.z; }
+    DE_DEV void set_surf(uint32_t pid, vec3 N, float alb, float ocean, float bathy) const {
+        Cold* c = &base[pid];
+        c->nx = N.x; c->ny = N.y; c->nz = N.z; c->alb = alb; c->ocean = ocean; c->bathy = bathy;
+    }
+    DE_DEV void get_surf(uint32_t pid, vec3& N, float& alb, float& ocean, float& bathy) const {
+        const Cold* c = &base[pid];
+        N = v3(c->nx, c->ny, c->nz); alb = c->alb; ocean = c->ocean; bathy = c->bathy;
+    }
+};
+
+// ---- the straight-line stages' bodies: one record in, the queue it goes to (or -1: the path has ended and its contribution is written)
+
+// EVENT: event resolution, light sample, branch — pathtracer.py:200-205, 369-393, 404, 441-444, and the miss epilogue :455-469.
+// p.x = (cloud_t, rmo_t, isect); W = D
+template <bool CLAMP, typename ColdT>
+DE_DEV int event_body(const RenderArgs& a, const FrameConsts& fc, const ColdT& cold, Path& p) {
+    int target = -1;
+    const int sc = m_sc(p.meta), node = m_node(p.meta);
+    const int rmo_event = m_event(p.meta);
+    const int cloud_event = rmo_event >> 4, gas_event = rmo_event & 15;
+    const float t = p.x[0], rmo_t = p.x[1], isect = p.x[2];
+    const vec3 D = p.W;
+    int event = gas_event;
+    float tt = rmo_t;
+    int id = m_evid(p.meta);
+    if (cloud_event > 0 && (t < rmo_t || gas_event == EV_NULL)) { tt = t; id = CLOUD_ID; event = cloud_event; }
+    if (sc > 9 && id == CLOUD_ID) id = ISOTROPIC_CLOUD_ID;
+    vec3 LD;
+    {   // sample_cone_oriented (lib/sampling.py:25-28), the light direction's basis from the frame constants
+        const vec3 cv = sample_cone(p.rng, fc.sun_cos_angle);
+        const vec3 bx = fc.sun_x, by = fc.sun_y, bn = fc.light_dir;
+        LD = v3((bx.x * cv.x + by.x * cv.y) + bn.x * cv.z, (bx.y * cv.x + by.y * cv.y) + bn.y * cv.z, (bx.z * cv.x + by.z * cv.y) + bn.z * cv.z);
+    }
+    bool end = false, miss = false;
+    if (event == EV_ABSORB) {
+        end = true;
+    } else if (event == EV_SCATTER) {
+        p.P = p.P + tt * D;
+        if (sc == 0) cold.set_thr_ls(p.pid, 1.0f, 0.0f);
+        cold.set_dir(p.pid, D);
+        p.W = LD;
+        const bool blocked = rsi(p.P, LD, DE_PLANET_R).y > 0.0f;
+        if (blocked) {
+            p.meta = m_make(1, node, sc, 0, id, 0);
+            p.x[0] = 0.0f; p.x[1] = 1.0f; p.x[2] = 1.0f;            // trg = 0 (direct_transmittance stays 0), trn, li = 1 marks "blocked"
+            target = Q_SCFIN;
+        } else {
+            const vec2_ atmos = rsi(p.P, LD, DE_ATMOS_UPPER);
+            float c_ts, c_tm; int below;
+            cloud_limits_of_ray(p.P, LD, &c_ts, &c_tm, &below);
+            p.meta = m_make(1, node, sc, below, id, 0);
+            const float t_start = de_max(0.0f, atmos.x);
+            float t_max = atmos.y;                                  // land_isection = -1
+            if (atmos.y < 0.0f) t_max = -1.0f;
+            if (t_start < t_max) {
+                p.x[0] = t_start; p.x[1] = t_max; p.x[2] = c_ts; p.x[3] = c_tm; p.x[4] = -1.0f;
+                target = Q_GAS;
+            } else {
+                target = enter_cloud(p, c_ts, c_tm, 1.0f, -1.0f);  // trg = 1
+            }
+        }
+    } else if (isect > 0.0f) {
+        p.P = p.P + D * isect;                                       // land_pos
+        if (sc == 0) cold.set_thr_ls(p.pid, 1.0f, 0.0f);
+        cold.set_dir(p.pid, D);
+        p.W = LD;
+        p.meta = m_make(2, node, sc, 0, id, 0);
+        target = Q_SURF;
+    } else {
+        end = true;
+        miss = (sc == 0);
+    }
+    if (end) {
+        const LambdaNode& L = a.nodes[node];
+        float Ls = (sc == 0) ? 0.0f : cold.get_ls(p.pid);
+        if (miss) {                                                  // pathtracer.py:455-463; D is still the primary direction
+            if (dot(fc.light_dir, D) > fc.sun_cos_angle) Ls += L.sun_power;
+            const vec3 stars_srgb = sphere_tap_rgb<CLAMP>(a.stars, normalized(D));
+            const float stars_power = v2::srgb_to_spectrum(L, stars_srgb);
+            Ls += stars_power * L.sun_power * 0.0000001f;
+        }
+        write_contrib(a, p.pid, Ls, node);
+    }
+    return target;
+}
+
+// SURF: land_normal (pathtracer.py:16-25), get_land_material (:276-312), emissive term, offset position (:406-422), head of the
+// shadow ray.  P = land_pos, W = LD.  Always continues to Q_ST.
+template <bool CLAMP, typename ColdT>
+DE_DEV int surf_body(const RenderArgs& a, const FrameConsts& fc, const ColdT& cold, Path& p) {
+    const float land_height_scale = fc.land_height_scale, e = fc.normal_eps;
+    const LambdaNode& L = a.nodes[m_node(p.meta)];
+    auto sdf_at = [&](vec3 Q) -> float {
+        const float len = length_nr(Q);
+        const vec3 nn = Q * de_rcp_nr(len);
+        const vec2_ uv = sphere_UV_map(nn);
+        const float tex = tap_r8<CLAMP>(a.topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
+        return len - DE_PLANET_R - land_height_scale * tex;
+    };
+    const float d0 = sdf_at(p.P);
+    vec3 N = v3(d0 - sdf_at(p.P - v3(e, 0.0f, 0.0f)), d0 - sdf_at(p.P - v3(0.0f, e, 0.0f)), d0 - sdf_at(p.P - v3(0.0f, 0.0f, e)));
+    N = normalized(N);
+    const vec3 nrm = normalized(p.P);
+    const vec2_ uv = sphere_UV_map(nrm);
+    const float uu = fract_(uv.x * 1.0f), vv = fract_(uv.y * 1.0f);
+    const float ocean = tap_r8<CLAMP>(a.ocean, uu, vv);
+    const vec3 tex = tap_rgb<CLAMP>(a.albedo, uu, vv);
+    vec3 land = mix3(lum3(tex), tex, 6.5f);
+    float greenery = sqr(land.y / lum(land));
+    greenery = smoothstep_(1.5f, 1.9f, greenery);
+    land = (1.0f * tex) / (greenery * 0.7f + 1.0f);
+    land = mix3(lum3(land), land, 1.4f - greenery * 0.45f);
+    land = mix3(land, (land * v3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));
+    const vec3 ocean_albedo = mix3(lum3(tex), tex, 0.75f) * 0.9f;
+    const vec3 albedo_srgb = mix3(land, ocean_albedo, ocean);
+    const float bathy = tap_r8<CLAMP>(a.bathy, uu, vv);
+    const float emissive = tap_r8<CLAMP>(a.emissive, uu, vv);
+    const float alb = v2::srgb_to_spectrum(L, albedo_srgb);
+    float thr, Ls;
+    cold.get_thr_ls(p.pid, thr, Ls);
+    cold.set_thr_ls(p.pid, thr, Ls + thr * emissive * L.night_power);
+    cold.set_surf(p.pid, N, alb, ocean, bathy);
+    p.P = p.P * fc.offset_scale;                                     // offset_pos
+    ray_head(p);                                                     // intersect_land(offset_pos, light_dir) head
+    return Q_ST;
+}
+
+// the end of a vertex, shared by SCFIN and SURFFIN: roulette (pathtracer.py:448-453), vertex limit, then either the contribution
+// or the next vertex's ray
+template <typename ColdT>
+DE_DEV int vertex_end(const RenderArgs& a, const ColdT& cold, Path& p, int node, int sc, float thr, float Ls, vec3 nd) {
+    bool end = false;
+    if (sc > 3) {
+        const float termination_p = de_max(0.05f, 1.0f - thr);
+        if (rng_next(p.rng) < termination_p) end = true;
+        else thr /= 1.0f - termination_p;
+    }
+    sc++;
+    if (!end && sc >= 25) end = true;
+    if (end) {
+        write_contrib(a, p.pid, Ls, node);
+        return -1;
+    }
+    cold.set_thr_ls(p.pid, thr, Ls);
+    p.W = nd;
+    p.meta = m_make(0, node, sc, 0, 0, 0);
+    ray_head(p);
+    return Q_ST;
+}
+
+// SCFIN: volume vertex — in-scattering, phase sampling (pathtracer.py:394-401).  p.x = (trg, trn, li); W = LD
+template <typename ColdT>
+DE_DEV int scfin_body(const RenderArgs& a, const FrameConsts& fc, const ColdT& cold, Path& p) {
+    const int node = m_node(p.meta), ev_id = m_evid(p.meta);
+    const int sc = m_sc(p.meta);
+    const LambdaNode& L = a.nodes[node];
+    float thr, Ls;
+    cold.get_thr_ls(p.pid, thr, Ls);
+    const vec3 D = cold.get_dir(p.pid), LD = p.W;
+    const float trg = p.x[0], trn = p.x[1], li = p.x[2];
+    const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
+    const float direct_phase = v2::evaluate_phase(fc, D, LD, ev_id, sc > 0);
+    Ls += thr * direct_tr * L.sun_irradiance * direct_phase;
+    float phase_div_pdf;
+    const vec3 nd = v2::sample_phase(fc, p.rng, D, ev_id, sc > 0, &phase_div_pdf);
+    thr *= phase_div_pdf;
+    return vertex_end(a, cold, p, node, sc, thr, Ls, nd);
+}
+
+// SURFFIN: surface vertex — direct light, cosine-weighted bounce (pathtracer.py:431-439).  p.x = (trg, trn, li); P = offset_pos, W = LD
+template <typename ColdT>
+DE_DEV int surffin_body(const RenderArgs& a, const ColdT& cold, Path& p) {
+    const int node = m_node(p.meta);
+    const int sc = m_sc(p.meta);
+    const LambdaNode& L = a.nodes[node];
+    float thr, Ls;
+    cold.get_thr_ls(p.pid, thr, Ls);
+    const vec3 D = cold.get_dir(p.pid), LD = p.W;
+    vec3 N; float alb, ocean, bathy;
+    cold.get_surf(p.pid, N, alb, ocean, bathy);
+    const float trg = p.x[0], trn = p.x[1], li = p.x[2];
+    const float direct_tr = trg * trn;
+    const bool visible = li < 0.0f;
+    float direct_ndl;
+    const float direct_brdf = earth_brdf(alb, ocean, bathy, -D, N, LD, &direct_ndl);
+    Ls += thr * direct_tr * (visible ? 1.0f : 0.0f) * L.sun_irradiance * direct_brdf * direct_ndl;
+    const vec3 view_dir = -D;
+    const vec3 nd = sample_hemisphere_cosine_weighted(p.rng, N);
+    float unused;
+    const float brdf = earth_brdf(alb, ocean, bathy, view_dir, N, nd, &unused);
+    thr *= brdf * (float)M_PI;
+    return vertex_end(a, cold, p, node, sc, thr, Ls, nd);
+}
+
 }  // namespace wf
 
 #define DE_V3_BLOCK 64
@@ -379,33 +616,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_primary_kernel(wf::Args A, con
         Path p;
         int target = -1;
         if (active) {
-            const uint32_t wq = w >> 6;
-            const uint32_t tile_k = (uint32_t)(((unsigned long long)wq * a.spp_magic) >> 40);
-            const uint32_t tile = a.tiles_identity ? tile_k : a.tiles[tile_k];
-            const int s_idx = (int)(wq - tile_k * (uint32_t)a.spp_count);
-            const int sub = (int)(w & 63u);
-            const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
-            const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
-            const uint32_t pixel = (uint32_t)(v * a.W + u);
-            rng_seed(p.rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
-            int node = 0;
-            if (!a.fixed_wavelength) {
-                const float sample = rng_next(p.rng);
-                node = 1;
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const float val = (it < 6) ? s_node_val[node] : a.node_val[node];
-                    if (val < sample) node = 2 * node + 1;
-                    else if (val > sample) node = 2 * node;
-                    else break;
-                }
-            }
-            p.pid = w;
-            p.W = v2::get_cast_dir(p.rng, fc, a.H, u, v);
-            p.P = fc.cam_pos;
-            p.meta = m_make(0, node, 0, 0, 0, 0);
-            p.x[5] = 0.0f;
-            ray_head(p);
+            new_path(a, fc, s_node_val, w, p);
 #ifndef DE_V3_LDS_TILE
             const float t = sphere_trace<CLAMP>(a, p, land_height_scale, escape_r, MAX_RAY_DIST);
             target = after_sphere_trace(p, t, MAX_RAY_DIST);
@@ -431,7 +642,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_primary_kernel(wf::Args A, con
 // intersect_land's loop (pathtracer.py:37-44), one step per trip; p.x = (t0, atm_x, atm_y, c_ts, c_tm)
 template <bool CLAMP>
 struct StStage {
-    const RenderArgs& a;
+    const TexR8 topo;                        // by value: what the loop reads stays in scalar registers for the stage's duration only
     float land_height_scale, escape_r, max_ray_dist;
     float t; int cnt;
     DE_DEV void begin(wf::Path& p) { t = p.x[0]; cnt = 0; }
@@ -445,7 +656,7 @@ struct StStage {
         }
         const vec3 n = Q * de_rcp_nr(len);
         const vec2_ uv = sphere_UV_map(n);
-        const float tex = tap_r8<CLAMP>(a.topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
+        const float tex = tap_r8<CLAMP>(topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
         const float sdf = len - DE_PLANET_R - land_height_scale * tex;
         t += sdf;
         cnt++;
@@ -458,7 +669,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_st_kernel(wf::Args A, const Fr
     using namespace wf;
     const FrameConsts& fc = *fcp;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
-    StStage<CLAMP> st{A.a, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+    StStage<CLAMP> st{A.a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
     const int targets[4] = {Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN};
     run_stage<DE_V3_SVC_ST>(A, A.q[Q_ST], st, targets);
 }
@@ -466,12 +677,13 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_st_kernel(wf::Args A, const Fr
 // ------------------------------------------------------------------------------------------------ GAS: delta / ratio tracking
 // pathtracer.py:91-112 (delta) and :130-141 (ratio) through the Rayleigh / Mie / ozone profiles; p.x = (t, tmax, c_ts, c_tm, X)
 struct GasStage {
-    const RenderArgs& a;
+    const LambdaNode* nodes;
+    const float* dens_table;
     float ext_r, ext_m, ext_o, rmaxr, t, tmax, trn;
     vec3 C;
     int kind, event, ev_id;
     DE_DEV void begin(wf::Path& p) {
-        const LambdaNode& L = a.nodes[wf::m_node(p.meta)];
+        const LambdaNode& L = nodes[wf::m_node(p.meta)];
         ext_r = L.ext_r; ext_m = L.ext_m; ext_o = L.ext_o; rmaxr = L.inv_max_ext_rmo;
         kind = wf::m_kind(p.meta);
         t = p.x[0]; tmax = p.x[1];
@@ -488,7 +700,7 @@ struct GasStage {
         const float h2 = de_max(len - DE_PLANET_R, 0.0f) * 2.0f;
         vec3 dens;
         if (h2 < (float)DE_DENS_TABLE_N) {
-            dens = dens_table_read(a.dens_table, (uint32_t)(int)h2);
+            dens = dens_table_read(dens_table, (uint32_t)(int)h2);
         } else {
             dens = get_density(len - DE_PLANET_R);
         }
@@ -527,7 +739,7 @@ struct GasStage {
 };
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_gas_kernel(wf::Args A) {
     using namespace wf;
-    GasStage st{A.a};
+    GasStage st{A.a.nodes, A.a.dens_table};
     const int targets[4] = {Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN};
     run_stage<DE_V3_SVC_GAS>(A, A.q[Q_GAS], st, targets);
 }
@@ -536,7 +748,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_gas_kernel(wf::Args A) {
 // the same loops with get_clouds_density (pathtracer.py:48-65); p.x = (t, tmax, aux = rmo_t | trg, X = isect | li)
 template <bool CLAMP>
 struct CloudStage {
-    const RenderArgs& a;
+    const TexR8 clouds;
     float ext_w, rmaxc, t, tmax, trn;
     vec3 C;
     int kind, cloud_event;
@@ -560,7 +772,7 @@ struct CloudStage {
         if (len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER) {
             const vec3 nrm = C * de_rcp_nr(len);
             const vec2_ uv = sphere_UV_map(nrm);
-            const float tex = tap_r8<CLAMP>(a.clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
+            const float tex = tap_r8<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
             const float h = (len - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
             const float split = 0.2f;
             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
@@ -589,18 +801,18 @@ struct CloudStage {
 template <bool CLAMP>
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_cloud_kernel(wf::Args A) {
     using namespace wf;
-    CloudStage<CLAMP> st{A.a};
+    CloudStage<CLAMP> st{A.a.clouds};
     const int targets[3] = {Q_EVENT, Q_SCFIN, Q_SURFFIN};
     run_stage<DE_V3_SVC_CLOUD>(A, A.q[Q_CLOUD], st, targets);
 }
 
 // ------------------------------------------------------------------------------------------------ EVENT: event resolution, light sample, branch
-// pathtracer.py:200-205, 369-393, 404, 441-444, and the miss epilogue :455-469.  p.x = (cloud_t, rmo_t, isect); W = D
 template <bool CLAMP>
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_event_kernel(wf::Args A, const FrameConsts* __restrict__ fcp) {
     using namespace wf;
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
+    const ColdPlain cold{A.cold};
     const Queue q = A.q[Q_EVENT];
     const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_gas = {0u, 0u}, o_cloud = {0u, 0u}, o_scfin = {0u, 0u}, o_surf = {0u, 0u};
@@ -611,75 +823,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_event_kernel(wf::Args A, const
         int target = -1;
         if (active) load_path(&q.rec[idx], p);
         if (active && p.pid == DE_V3_HOLE) active = false;
-        if (active) {
-            const int sc = m_sc(p.meta), node = m_node(p.meta);
-            const int rmo_event = m_event(p.meta);
-            const int cloud_event = rmo_event >> 4, gas_event = rmo_event & 15;
-            const float t = p.x[0], rmo_t = p.x[1], isect = p.x[2];
-            const vec3 D = p.W;
-            int event = gas_event;
-            float tt = rmo_t;
-            int id = m_evid(p.meta);
-            if (cloud_event > 0 && (t < rmo_t || gas_event == EV_NULL)) { tt = t; id = CLOUD_ID; event = cloud_event; }
-            if (sc > 9 && id == CLOUD_ID) id = ISOTROPIC_CLOUD_ID;
-            vec3 LD;
-            {   // sample_cone_oriented (lib/sampling.py:25-28), the light direction's basis from the frame constants
-                const vec3 cv = sample_cone(p.rng, fc.sun_cos_angle);
-                const vec3 bx = fc.sun_x, by = fc.sun_y, bn = fc.light_dir;
-                LD = v3((bx.x * cv.x + by.x * cv.y) + bn.x * cv.z, (bx.y * cv.x + by.y * cv.y) + bn.y * cv.z, (bx.z * cv.x + by.z * cv.y) + bn.z * cv.z);
-            }
-            Cold* cold = &A.cold[p.pid];
-            bool end = false, miss = false;
-            if (event == EV_ABSORB) {
-                end = true;
-            } else if (event == EV_SCATTER) {
-                p.P = p.P + tt * D;
-                if (sc == 0) { cold->thr = 1.0f; cold->Ls = 0.0f; }
-                cold->dx = D.x; cold->dy = D.y; cold->dz = D.z;
-                p.W = LD;
-                const bool blocked = rsi(p.P, LD, DE_PLANET_R).y > 0.0f;
-                if (blocked) {
-                    p.meta = m_make(1, node, sc, 0, id, 0);
-                    p.x[0] = 0.0f; p.x[1] = 1.0f; p.x[2] = 1.0f;            // trg = 0 (direct_transmittance stays 0), trn, li = 1 marks "blocked"
-                    target = Q_SCFIN;
-                } else {
-                    const vec2_ atmos = rsi(p.P, LD, DE_ATMOS_UPPER);
-                    float c_ts, c_tm; int below;
-                    cloud_limits_of_ray(p.P, LD, &c_ts, &c_tm, &below);
-                    p.meta = m_make(1, node, sc, below, id, 0);
-                    const float t_start = de_max(0.0f, atmos.x);
-                    float t_max = atmos.y;                                  // land_isection = -1
-                    if (atmos.y < 0.0f) t_max = -1.0f;
-                    if (t_start < t_max) {
-                        p.x[0] = t_start; p.x[1] = t_max; p.x[2] = c_ts; p.x[3] = c_tm; p.x[4] = -1.0f;
-                        target = Q_GAS;
-                    } else {
-                        target = enter_cloud(p, c_ts, c_tm, 1.0f, -1.0f);  // trg = 1
-                    }
-                }
-            } else if (isect > 0.0f) {
-                p.P = p.P + D * isect;                                       // land_pos
-                if (sc == 0) { cold->thr = 1.0f; cold->Ls = 0.0f; }
-                cold->dx = D.x; cold->dy = D.y; cold->dz = D.z;
-                p.W = LD;
-                p.meta = m_make(2, node, sc, 0, id, 0);
-                target = Q_SURF;
-            } else {
-                end = true;
-                miss = (sc == 0);
-            }
-            if (end) {
-                const LambdaNode& L = a.nodes[node];
-                float Ls = (sc == 0) ? 0.0f : cold->Ls;
-                if (miss) {                                                  // pathtracer.py:455-463; D is still the primary direction
-                    if (dot(fc.light_dir, D) > fc.sun_cos_angle) Ls += L.sun_power;
-                    const vec3 stars_srgb = sphere_tap_rgb<CLAMP>(a.stars, normalized(D));
-                    const float stars_power = v2::srgb_to_spectrum(L, stars_srgb);
-                    Ls += stars_power * L.sun_power * 0.0000001f;
-                }
-                write_contrib(a, p.pid, Ls, node);
-            }
-        }
+        if (active) target = event_body<CLAMP>(a, fc, cold, p);
         push(A.q[Q_GAS], o_gas, p, target == Q_GAS);
         push(A.q[Q_CLOUD], o_cloud, p, target == Q_CLOUD);
         push(A.q[Q_SCFIN], o_scfin, p, target == Q_SCFIN);
@@ -689,68 +833,33 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_event_kernel(wf::Args A, const
 }
 
 // ------------------------------------------------------------------------------------------------ SURF: normal, material, shadow-ray set-up
-// land_normal (pathtracer.py:16-25), get_land_material (:276-312), emissive term, offset position (:406-422).  P = land_pos, W = LD
 template <bool CLAMP>
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_surf_kernel(wf::Args A, const FrameConsts* __restrict__ fcp) {
     using namespace wf;
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
+    const ColdPlain cold{A.cold};
     const Queue q = A.q[Q_SURF];
     const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
-    const float land_height_scale = fc.land_height_scale, e = fc.normal_eps;
     begin_drain(q);
     uint32_t chunk = 0xffffffffu, idx; bool active;
     while (next_chunk(n, &chunk, &idx, &active)) {
         Path p;
         if (active) load_path(&q.rec[idx], p);
         if (active && p.pid == DE_V3_HOLE) active = false;
-        if (active) {
-            const LambdaNode& L = a.nodes[m_node(p.meta)];
-            Cold* cold = &A.cold[p.pid];
-            auto sdf_at = [&](vec3 Q) -> float {
-                const float len = length_nr(Q);
-                const vec3 nn = Q * de_rcp_nr(len);
-                const vec2_ uv = sphere_UV_map(nn);
-                const float tex = tap_r8<CLAMP>(a.topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
-                return len - DE_PLANET_R - land_height_scale * tex;
-            };
-            const float d0 = sdf_at(p.P);
-            vec3 N = v3(d0 - sdf_at(p.P - v3(e, 0.0f, 0.0f)), d0 - sdf_at(p.P - v3(0.0f, e, 0.0f)), d0 - sdf_at(p.P - v3(0.0f, 0.0f, e)));
-            N = normalized(N);
-            const vec3 nrm = normalized(p.P);
-            const vec2_ uv = sphere_UV_map(nrm);
-            const float uu = fract_(uv.x * 1.0f), vv = fract_(uv.y * 1.0f);
-            const float ocean = tap_r8<CLAMP>(a.ocean, uu, vv);
-            const vec3 tex = tap_rgb<CLAMP>(a.albedo, uu, vv);
-            vec3 land = mix3(lum3(tex), tex, 6.5f);
-            float greenery = sqr(land.y / lum(land));
-            greenery = smoothstep_(1.5f, 1.9f, greenery);
-            land = (1.0f * tex) / (greenery * 0.7f + 1.0f);
-            land = mix3(lum3(land), land, 1.4f - greenery * 0.45f);
-            land = mix3(land, (land * v3(255.0f, 128.0f, 64.0f)) / 255.0f, 0.2f * (1.0f - greenery));
-            const vec3 ocean_albedo = mix3(lum3(tex), tex, 0.75f) * 0.9f;
-            const vec3 albedo_srgb = mix3(land, ocean_albedo, ocean);
-            const float bathy = tap_r8<CLAMP>(a.bathy, uu, vv);
-            const float emissive = tap_r8<CLAMP>(a.emissive, uu, vv);
-            const float alb = v2::srgb_to_spectrum(L, albedo_srgb);
-            cold->Ls = cold->Ls + cold->thr * emissive * L.night_power;
-            cold->nx = N.x; cold->ny = N.y; cold->nz = N.z;
-            cold->alb = alb; cold->ocean = ocean; cold->bathy = bathy;
-            p.P = p.P * fc.offset_scale;                                     // offset_pos
-            ray_head(p);                                                     // intersect_land(offset_pos, light_dir) head
-        }
+        if (active) surf_body<CLAMP>(a, fc, cold, p);
         push(A.q[Q_ST], o_st, p, active);
     }
     close_out(A.q[Q_ST], o_st);
 }
 
 // ------------------------------------------------------------------------------------------------ SCFIN: volume vertex
-// in-scattering, phase sampling, roulette (pathtracer.py:394-401, 448-453), then the next vertex's ray.  p.x = (trg, trn, li); W = LD
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_scfin_kernel(wf::Args A, const FrameConsts* __restrict__ fcp) {
     using namespace wf;
     const RenderArgs& a = A.a;
     const FrameConsts& fc = *fcp;
+    const ColdPlain cold{A.cold};
     const Queue q = A.q[Q_SCFIN];
     const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
@@ -761,48 +870,17 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_scfin_kernel(wf::Args A, const
         bool go = false;
         if (active) load_path(&q.rec[idx], p);
         if (active && p.pid == DE_V3_HOLE) active = false;
-        if (active) {
-            const int node = m_node(p.meta), ev_id = m_evid(p.meta);
-            int sc = m_sc(p.meta);
-            const LambdaNode& L = a.nodes[node];
-            Cold* cold = &A.cold[p.pid];
-            float thr = cold->thr, Ls = cold->Ls;
-            const vec3 D = v3(cold->dx, cold->dy, cold->dz), LD = p.W;
-            const float trg = p.x[0], trn = p.x[1], li = p.x[2];
-            const float direct_tr = (li > 0.0f) ? 0.0f : trg * trn;
-            const float direct_phase = v2::evaluate_phase(fc, D, LD, ev_id, sc > 0);
-            Ls += thr * direct_tr * L.sun_irradiance * direct_phase;
-            float phase_div_pdf;
-            const vec3 nd = v2::sample_phase(fc, p.rng, D, ev_id, sc > 0, &phase_div_pdf);
-            thr *= phase_div_pdf;
-            bool end = false;
-            if (sc > 3) {
-                const float termination_p = de_max(0.05f, 1.0f - thr);
-                if (rng_next(p.rng) < termination_p) end = true;
-                else thr /= 1.0f - termination_p;
-            }
-            sc++;
-            if (!end && sc >= 25) end = true;
-            if (end) {
-                write_contrib(a, p.pid, Ls, node);
-            } else {
-                cold->thr = thr; cold->Ls = Ls;
-                p.W = nd;
-                p.meta = m_make(0, node, sc, 0, 0, 0);
-                ray_head(p);
-                go = true;
-            }
-        }
+        if (active) go = scfin_body(a, fc, cold, p) == Q_ST;
         push(A.q[Q_ST], o_st, p, go);
     }
     close_out(A.q[Q_ST], o_st);
 }
 
 // ------------------------------------------------------------------------------------------------ SURFFIN: surface vertex
-// direct light, cosine-weighted bounce, roulette (pathtracer.py:431-439, 448-453).  p.x = (trg, trn, li); P = offset_pos, W = LD
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_surffin_kernel(wf::Args A, const FrameConsts* __restrict__ fcp) {
     using namespace wf;
     const RenderArgs& a = A.a;
+    const ColdPlain cold{A.cold};
     const Queue q = A.q[Q_SURFFIN];
     const uint32_t n = min(q.ctl[0], A.capacity);
     Out o_st = {0u, 0u};
@@ -813,43 +891,7 @@ __global__ void __launch_bounds__(DE_V3_BLOCK) v3_surffin_kernel(wf::Args A, con
         bool go = false;
         if (active) load_path(&q.rec[idx], p);
         if (active && p.pid == DE_V3_HOLE) active = false;
-        if (active) {
-            const int node = m_node(p.meta);
-            int sc = m_sc(p.meta);
-            const LambdaNode& L = a.nodes[node];
-            Cold* cold = &A.cold[p.pid];
-            float thr = cold->thr, Ls = cold->Ls;
-            const vec3 D = v3(cold->dx, cold->dy, cold->dz), N = v3(cold->nx, cold->ny, cold->nz), LD = p.W;
-            const float alb = cold->alb, ocean = cold->ocean, bathy = cold->bathy;
-            const float trg = p.x[0], trn = p.x[1], li = p.x[2];
-            const float direct_tr = trg * trn;
-            const bool visible = li < 0.0f;
-            float direct_ndl;
-            const float direct_brdf = earth_brdf(alb, ocean, bathy, -D, N, LD, &direct_ndl);
-            Ls += thr * direct_tr * (visible ? 1.0f : 0.0f) * L.sun_irradiance * direct_brdf * direct_ndl;
-            const vec3 view_dir = -D;
-            const vec3 nd = sample_hemisphere_cosine_weighted(p.rng, N);
-            float unused;
-            const float brdf = earth_brdf(alb, ocean, bathy, view_dir, N, nd, &unused);
-            thr *= brdf * (float)M_PI;
-            bool end = false;
-            if (sc > 3) {
-                const float termination_p = de_max(0.05f, 1.0f - thr);
-                if (rng_next(p.rng) < termination_p) end = true;
-                else thr /= 1.0f - termination_p;
-            }
-            sc++;
-            if (!end && sc >= 25) end = true;
-            if (end) {
-                write_contrib(a, p.pid, Ls, node);
-            } else {
-                cold->thr = thr; cold->Ls = Ls;
-                p.W = nd;
-                p.meta = m_make(0, node, sc, 0, 0, 0);
-                ray_head(p);
-                go = true;
-            }
-        }
+        if (active) go = surffin_body(a, cold, p) == Q_ST;
         push(A.q[Q_ST], o_st, p, go);
     }
     close_out(A.q[Q_ST], o_st);

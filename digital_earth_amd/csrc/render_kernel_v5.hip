@@ -1,0 +1,560 @@
+// render_kernel_v5.hip — path_tracer (pathtracer.py:316-469) as ONE PERSISTENT KERNEL: a stage scheduler over chunked HBM queues.
+//
+// Why.  render_kernel_v3 runs the integrator as a level-synchronous pipeline: ten launches per path vertex, each draining one stage
+// queue with every wave in the same loop.  Its waves are coherent, but (i) a SIMD that holds waves of ONE class cannot cover that
+// class's dependent loads (gas 22 %, cloud 37 % of the VALU issue ceiling), (ii) every launch ends with its own tail, (iii) the
+// deep vertex rounds are all tail, which is why the default handed them to render_kernel_v2.  Here the same seven stage bodies
+// (shared with render_kernel_v3.hip: one statement of the integrator per family) run inside one launch of persistent one-wave
+// workgroups.  A wave asks the scheduler for the fullest queue, claims chunks of 64 records from it, runs that stage's body on them
+// — the loop stages with persistent lanes that refill from the queue, exactly as in v3 — and appends the results to the queues of
+// the next stages; when its queue runs dry it goes back to the scheduler.  Waves of different stages share every SIMD, there is no
+// level barrier and no hand-over, and new paths are only started when no queued work is left for a wave: the population in flight
+// stays near the minimum that keeps the machine busy (a few hundred MB of queue memory instead of 512 B per path of a batch).
+//
+// Results are IDENTICAL to render_kernel_v2 / _v3 / the CPU oracle: every path runs the same arithmetic in the same order on its
+// own RNG stream; only where and when changes.
+//
+// Inter-workgroup visibility (the per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores):
+// records and cold records are written THROUGH (sc1) and read with sc1 loads; a chunk is published — one agent-scope store of its
+// ring cell — only after the writing wave has drained its stores (s_waitcnt vmcnt(0)); control words and ring cells are agent-scope
+// atomics.  No fences, no spinning on data: the only waits are on a ring cell between its producer's ticket and its store (a few
+// hundred ns), and on the free-chunk ring when the pool is exhausted (sized so that it is not).  Every wait is bounded: a wave that
+// waits too long raises the abort word, every wave leaves, and the host reports DE_ERR_HIP instead of a hung GPU.
+#include "de_kernels.h"
+
+namespace ps {
+
+using wf::Path;
+using wf::NQ;
+using wf::Q_ST; using wf::Q_GAS; using wf::Q_CLOUD; using wf::Q_EVENT; using wf::Q_SURF; using wf::Q_SCFIN; using wf::Q_SURFFIN;
+
+enum { Q_PRIMARY = NQ, Q_EXIT = NQ + 1 };
+#define DE_V5_CH 64u                       // records per chunk = one wave-load
+#define DE_V5_EMPTY 0xffffffffu
+#define DE_V5_NONE 0xffffffffu
+#define DE_V5_CTL_STRIDE 32u               // one control word per 128-byte line
+#define DE_V5_MAX_SHARDS 8
+// control words (index x DE_V5_CTL_STRIDE dwords)
+enum { C_WORK = 0, C_DONE = 1, C_ABORT = 2, C_FREE_HEAD = 3, C_FREE_TAIL = 4, C_STAT0 = 8, C_QUEUE0 = 40, C_WORDS = C_QUEUE0 + 2 * NQ * DE_V5_MAX_SHARDS };
+// statistics (C_STAT0 + k): 0-7 records taken per stage (7 = primary), 8-15 wave-cycles (s_memtime / 64) per stage, 16 idle loops,
+// 17 partial chunks published, 18 failed claims, 19 stage entries, 20 chunk allocations from the global ring, 21 steals
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_PARTIAL = 17, ST_CLAIMFAIL = 18, ST_ENTRIES = 19, ST_GALLOC = 20, ST_STEAL = 21, ST_SCHED_CYC = 22, ST_N = 24 };
+enum { ERR_CELL_TIMEOUT = 1, ERR_POOL_EMPTY = 2, ERR_IDLE_WATCHDOG = 3 };
+
+struct Args {
+    const RenderArgs* ra;       // the launch's RenderArgs in device memory (written by v5_init_kernel): each stage reads what it needs
+                                // through a pointer the compiler cannot see through, so that nothing of it stays live between stages
+    uint4* pool;                // pool_chunks x DE_V5_CH x 64-byte records
+    uint32_t* ctl;              // C_WORDS x DE_V5_CTL_STRIDE dwords
+    uint32_t* rings;            // [n_shards x NQ][ring_mask + 1] cells: chunk id x 128 + records, DE_V5_EMPTY when free
+    uint32_t* free_ring;        // [pool_chunks] chunk ids
+    unsigned long long* cold;   // 8 x 8 bytes per path
+    uint32_t* status;           // host-visible: [0] abort code (0 = clean)
+    uint32_t n_items, pool_chunks, ring_mask, n_shards;
+    uint32_t reserve_chunks;    // new paths are started only while at least this many chunks are free
+    uint32_t claim_k;           // chunks per claim (1..4)
+    uint32_t age_max;           // a partial output chunk is published once it is this old (ticks of the 100 MHz constant clock)
+    uint32_t closers;           // workgroups that stay until the last path has ended; the others leave when they run out of work
+    uint32_t idle_limit;        // watchdog: scheduler rounds without work before a wave raises the abort word
+};
+template <int... T> struct Targets {};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define DE_V5_SC1 16            // aux bits of the raw buffer builtins on gfx950: 16 = sc1 (write-through / L1 bypass)
+
+DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DE_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DE_DEV void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DE_DEV uint32_t add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// records: four 16-byte sc1 accesses through a buffer descriptor over the pool (<= 4 GB)
+DE_DEV void load_rec(__amdgpu_buffer_rsrc_t rs, uint32_t rec, Path& p) {
+    const int off = (int)(rec * 64u);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, DE_V5_SC1);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, DE_V5_SC1);
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, DE_V5_SC1);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, DE_V5_SC1);
+    p.pid = a.x; p.meta = a.y; p.rng.s0 = a.z; p.rng.s1 = a.w; p.rng.draws = 0;
+    p.P = v3(wf::asf(b.x), wf::asf(b.y), wf::asf(b.z)); p.W = v3(wf::asf(b.w), wf::asf(c.x), wf::asf(c.y));
+    p.x[0] = wf::asf(c.z); p.x[1] = wf::asf(c.w); p.x[2] = wf::asf(d.x); p.x[3] = wf::asf(d.y); p.x[4] = wf::asf(d.z); p.x[5] = wf::asf(d.w);
+}
+DE_DEV void store_rec(__amdgpu_buffer_rsrc_t rs, uint32_t rec, const Path& p) {
+    const int off = (int)(rec * 64u);
+    u32x4 a, b, c, d;
+    a.x = p.pid; a.y = p.meta; a.z = p.rng.s0; a.w = p.rng.s1;
+    b.x = wf::asu(p.P.x); b.y = wf::asu(p.P.y); b.z = wf::asu(p.P.z); b.w = wf::asu(p.W.x);
+    c.x = wf::asu(p.W.y); c.y = wf::asu(p.W.z); c.z = wf::asu(p.x[0]); c.w = wf::asu(p.x[1]);
+    d.x = wf::asu(p.x[2]); d.y = wf::asu(p.x[3]); d.z = wf::asu(p.x[4]); d.w = wf::asu(p.x[5]);
+    __builtin_amdgcn_raw_buffer_store_b128(a, rs, off, 0, DE_V5_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(b, rs, off + 16, 0, DE_V5_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(c, rs, off + 32, 0, DE_V5_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, off + 48, 0, DE_V5_SC1);
+}
+
+// cold records: 8-byte agent-scope (sc1) accesses, any buffer size.  Layout (8-byte words): 0 (thr, Ls), 1 (dx, dy), 2 (dz, -),
+// 3 (nx, ny), 4 (nz, alb), 5 (ocean, bathy).  A path's cold record is written by the wave that then queues the path's record
+// (drained before the chunk is published) and read by the wave that claimed it: ordered by the chunk hand-over.
+struct ColdWT {
+    unsigned long long* base;
+    DE_DEV static unsigned long long pack(float a, float b) { return (unsigned long long)wf::asu(a) | ((unsigned long long)wf::asu(b) << 32); }
+    DE_DEV unsigned long long ld(uint32_t pid, int k) const { return __hip_atomic_load(base + (size_t)pid * 8u + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    DE_DEV void st(uint32_t pid, int k, unsigned long long v) const { __hip_atomic_store(base + (size_t)pid * 8u + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    DE_DEV void get_thr_ls(uint32_t pid, float& thr, float& Ls) const { const unsigned long long v = ld(pid, 0); thr = wf::asf((uint32_t)v); Ls = wf::asf((uint32_t)(v >> 32)); }
+    DE_DEV float get_ls(uint32_t pid) const { return wf::asf((uint32_t)(ld(pid, 0) >> 32)); }
+    DE_DEV void set_thr_ls(uint32_t pid, float thr, float Ls) const { st(pid, 0, pack(thr, Ls)); }
+    DE_DEV vec3 get_dir(uint32_t pid) const {
+        const unsigned long long a = ld(pid, 1), b = ld(pid, 2);
+        return v3(wf::asf((uint32_t)a), wf::asf((uint32_t)(a >> 32)), wf::asf((uint32_t)b));
+    }
+    DE_DEV void set_dir(uint32_t pid, vec3 D) const { st(pid, 1, pack(D.x, D.y)); st(pid, 2, pack(D.z, 0.0f)); }
+    DE_DEV void set_surf(uint32_t pid, vec3 N, float alb, float ocean, float bathy) const {
+        st(pid, 3, pack(N.x, N.y)); st(pid, 4, pack(N.z, alb)); st(pid, 5, pack(ocean, bathy));
+    }
+    DE_DEV void get_surf(uint32_t pid, vec3& N, float& alb, float& ocean, float& bathy) const {
+        const unsigned long long a = ld(pid, 3), b = ld(pid, 4), c = ld(pid, 5);
+        N = v3(wf::asf((uint32_t)a), wf::asf((uint32_t)(a >> 32)), wf::asf((uint32_t)b));
+        alb = wf::asf((uint32_t)(b >> 32)); ocean = wf::asf((uint32_t)c); bathy = wf::asf((uint32_t)(c >> 32));
+    }
+};
+
+// Everything a wave carries between stages.  All members are wave-uniform (SGPRs) except `stash`: lane i holds free chunk id i.
+template <bool CLAMP, bool STATS>
+struct Wave {
+    const Args& A;
+    const float* s_node_val;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t shard;
+    // output side: one partially filled chunk per target queue
+    uint32_t oc[NQ], of[NQ], oa[NQ];
+    // free chunks held by this wave
+    uint32_t stash, n_stash;
+    // input side: the queue being drained
+    uint32_t in_ring;           // index of the ring ((shard x NQ + q), possibly another shard's when stealing)
+    uint32_t in_chunk, in_lo, in_hi, in_h, in_n;
+    uint32_t done_local;
+    bool primary_left, aborted;
+    // statistics
+    uint32_t st_recs[NQ + 1], st_misc[8];
+    unsigned long long st_cyc[NQ + 1], st_sched, t_mark;
+
+    DE_DEV uint32_t* ctl(uint32_t k) const { return A.ctl + k * DE_V5_CTL_STRIDE; }
+    DE_DEV uint32_t* q_head(uint32_t ring) const { return ctl(C_QUEUE0 + 2u * ring); }
+    DE_DEV uint32_t* q_tail(uint32_t ring) const { return ctl(C_QUEUE0 + 2u * ring + 1u); }
+    DE_DEV uint32_t* ring_cells(uint32_t ring) const { return A.rings + (size_t)ring * ((size_t)A.ring_mask + 1u); }
+
+    DE_DEV void raise(uint32_t code) {
+        if (lane_id() == 0) {
+            st_agent(ctl(C_ABORT), code);
+            __hip_atomic_store(A.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        aborted = true;
+    }
+    DE_DEV bool abort_seen() { if (!aborted && uni(ld_agent(ctl(C_ABORT))) != 0u) aborted = true; return aborted; }
+
+    // ---- ring cells: the producer takes a ticket (tail), then stores the cell; the consumer that owns the ticket waits for the store
+    DE_DEV uint32_t take_cell(uint32_t* cells, uint32_t mask, uint32_t idx) {
+        uint32_t c = DE_V5_EMPTY;
+        if (lane_id() == 0) {
+            uint32_t* cell = cells + (idx & mask);
+#pragma nounroll
+            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+                c = ld_agent(cell);
+                if (c != DE_V5_EMPTY) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (c != DE_V5_EMPTY) st_agent(cell, DE_V5_EMPTY);
+        }
+        c = uni(c);
+        if (c == DE_V5_EMPTY) raise(ERR_CELL_TIMEOUT);
+        return c;
+    }
+    // claim up to kmax entries of a ring whose head / tail words are given: a compare-and-swap on the head, never past the tail
+    DE_DEV uint32_t claim(uint32_t* head, uint32_t* tail, uint32_t kmin, uint32_t kmax, uint32_t* first) {
+        uint32_t got = 0, hh = 0;
+        if (lane_id() == 0) {
+            uint32_t h = ld_agent(head);
+#pragma nounroll
+            for (int tries = 0; tries < 8; ++tries) {
+                const uint32_t t = ld_agent(tail);
+                const int avail = (int)(t - h);
+                if (avail < (int)kmin) break;
+                const uint32_t k = (uint32_t)avail < kmax ? (uint32_t)avail : kmax;
+                uint32_t expected = h;
+                if (__hip_atomic_compare_exchange_strong(head, &expected, h + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = k; hh = h; break; }
+                h = expected;
+            }
+        }
+        *first = uni(hh);
+        return uni(got);
+    }
+
+    // ---- free chunks.  The wave keeps a few in `stash` (lane i = entry i).  ensure_stash() — called once per service / chunk / pass,
+    // i.e. between any two of its calls at most eight chunks are taken — is the only place that goes to the device-wide ring for more.
+    DE_DEV void ensure_stash() {
+        if (n_stash >= 8u) return;
+        uint32_t first = 0, k = 0;
+#pragma nounroll
+        for (uint32_t spins = 0; spins < (1u << 16) && !abort_seen(); ++spins) {
+            k = claim(ctl(C_FREE_HEAD), ctl(C_FREE_TAIL), 8u, 8u, &first);
+            if (k) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!k) { if (!aborted) raise(ERR_POOL_EMPTY); return; }
+        if (STATS) st_misc[ST_GALLOC - ST_IDLE]++;
+        const uint32_t l = (uint32_t)lane_id();
+        uint32_t c = 0u;
+        if (l >= n_stash && l < n_stash + k) {
+            uint32_t* cell = A.free_ring + ((first + (l - n_stash)) & (A.pool_chunks - 1u));
+            c = DE_V5_EMPTY;
+#pragma nounroll
+            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+                c = ld_agent(cell);
+                if (c != DE_V5_EMPTY) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (c != DE_V5_EMPTY) st_agent(cell, DE_V5_EMPTY);
+            stash = c;
+        }
+        if (__ballot(c == DE_V5_EMPTY) != 0ull) { raise(ERR_CELL_TIMEOUT); return; }
+        n_stash += k;
+    }
+    DE_DEV uint32_t alloc_chunk() {
+        if (n_stash == 0u) { if (!aborted) raise(ERR_POOL_EMPTY); return 0u; }      // cannot happen (ensure_stash); chunk 0 is scribbled on and the frame reported as failed
+        n_stash--;
+        return (uint32_t)__builtin_amdgcn_readlane((int)stash, (int)n_stash);
+    }
+    DE_DEV void free_chunk(uint32_t chunk) {
+        if ((uint32_t)lane_id() == n_stash) stash = chunk;
+        n_stash++;
+        if (n_stash >= 40u) {           // give sixteen back
+            uint32_t i = 0;
+            if (lane_id() == 0) i = add_agent(ctl(C_FREE_TAIL), 16u);
+            i = uni(i);
+            const uint32_t l = (uint32_t)lane_id();
+            if (l >= n_stash - 16u && l < n_stash) st_agent(A.free_ring + ((i + (l - (n_stash - 16u))) & (A.pool_chunks - 1u)), stash);
+            n_stash -= 16u;
+        }
+    }
+
+    // ---- output side
+    DE_DEV void publish(uint32_t q, uint32_t chunk, uint32_t count) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's record and cold stores have been written through
+        if (lane_id() == 0) {
+            const uint32_t ring = shard * NQ + q;
+            const uint32_t i = add_agent(q_tail(ring), 1u);
+            st_agent(ring_cells(ring) + (i & A.ring_mask), chunk * 128u + count);
+        }
+    }
+    template <int Q>
+    DE_DEV void push(const Path& p, bool pred) {
+        const unsigned long long mask = __ballot(pred);
+        if (mask == 0ull) return;
+        const uint32_t n = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+        if (oc[Q] == DE_V5_NONE) { oc[Q] = alloc_chunk(); of[Q] = 0u; oa[Q] = now(); }
+        const uint32_t rem = DE_V5_CH - of[Q];
+        if (pred && rank < rem) store_rec(rs, oc[Q] * DE_V5_CH + of[Q] + rank, p);
+        if (n >= rem) {
+            publish(Q, oc[Q], DE_V5_CH);
+            if (n > rem) {
+                oc[Q] = alloc_chunk(); of[Q] = n - rem; oa[Q] = now();
+                if (pred && rank >= rem) store_rec(rs, oc[Q] * DE_V5_CH + (rank - rem), p);
+            } else { oc[Q] = DE_V5_NONE; of[Q] = 0u; }
+        } else of[Q] += n;
+    }
+    // publish partially filled chunks: all of them (an idle wave: whatever it holds may be the only work left), or those that have
+    // waited for age_max scheduler rounds (a record must not sit in a rarely used target's chunk until the end of the launch)
+    DE_DEV bool flush_outs(bool all) {
+        bool any = false;
+        const uint32_t t = now();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (oc[q] != DE_V5_NONE && of[q] > 0u && (all || t - oa[q] >= A.age_max)) {
+                publish((uint32_t)q, oc[q], of[q]);
+                oc[q] = DE_V5_NONE; of[q] = 0u;
+                if (STATS) st_misc[ST_PARTIAL - ST_IDLE]++;
+                any = true;
+            }
+        }
+        return any;
+    }
+    DE_DEV static uint32_t now() { return (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+
+    // ---- input side
+    DE_DEV bool next_input() {
+        if (in_chunk != DE_V5_NONE) { free_chunk(in_chunk); in_chunk = DE_V5_NONE; }
+        in_lo = in_hi = 0u;
+        if (in_n == 0u) {
+            in_n = claim(q_head(in_ring), q_tail(in_ring), 1u, A.claim_k, &in_h);
+            if (in_n == 0u) return false;
+        }
+        const uint32_t cell = take_cell(ring_cells(in_ring), A.ring_mask, in_h);
+        in_h++; in_n--;
+        if (cell == DE_V5_EMPTY) return false;
+        in_chunk = cell >> 7; in_lo = 0u; in_hi = cell & 127u;
+        return true;
+    }
+    DE_DEV void leave_input() {
+        if (in_chunk != DE_V5_NONE && in_lo == in_hi) { free_chunk(in_chunk); in_chunk = DE_V5_NONE; }
+    }
+
+    DE_DEV void mark(int stage) {
+        if (!STATS) return;
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (stage >= 0) st_cyc[stage] += t - t_mark; else st_sched += t - t_mark;
+        t_mark = t;
+    }
+
+    // ---- the scheduler: which stage this wave runs next.  Returns a queue id (its first chunks are claimed: in_ring / in_h / in_n),
+    // Q_PRIMARY, or Q_EXIT.
+    DE_DEV int schedule() {
+        uint32_t idle = 0;
+        for (;;) {
+            if (abort_seen()) return Q_EXIT;
+            flush_outs(false);
+            ensure_stash();
+            // one look at every queue: lane l reads head and tail of ring l; lanes 62 / 63 the work counter and the free-chunk count
+            const uint32_t n_rings = A.n_shards * NQ;
+            int ready = 0;
+            const uint32_t l = (uint32_t)lane_id();
+            if (l < n_rings) { const uint32_t h = ld_agent(q_head(l)), t = ld_agent(q_tail(l)); ready = (int)(t - h); }
+            else if (l == 62u) ready = (int)ld_agent(ctl(C_WORK));
+            else if (l == 63u) ready = (int)(ld_agent(ctl(C_FREE_TAIL)) - ld_agent(ctl(C_FREE_HEAD)));
+            const uint32_t work_next = (uint32_t)__builtin_amdgcn_readlane(ready, 62);
+            const int free_chunks = __builtin_amdgcn_readlane(ready, 63);
+            if (work_next >= A.n_items) primary_left = false;
+            // the fullest queue of this wave's shard; another shard's when its own has nothing
+            int best_q = -1, best = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = __builtin_amdgcn_readlane(ready, (int)(shard * NQ) + q);
+                if (r > best) { best = r; best_q = q; }
+            }
+            uint32_t ring = shard * NQ + (uint32_t)(best_q < 0 ? 0 : best_q);
+            if (best_q < 0 && A.n_shards > 1u) {
+                const unsigned long long m = __ballot(l < n_rings && ready > 0);
+                if (m != 0ull) {
+                    // start looking after this wave's own rings so that the thieves spread over the victims
+                    const uint32_t rot = (shard * NQ + NQ) & 63u;
+                    const unsigned long long mr = (m >> rot) | (rot ? (m << (64u - rot)) : 0ull);
+                    ring = ((uint32_t)__builtin_ctzll(mr) + rot) & 63u;
+                    best_q = (int)(ring % NQ);
+                    if (STATS) st_misc[ST_STEAL - ST_IDLE]++;
+                }
+            }
+            if (best_q >= 0) {
+                in_ring = ring;
+                in_n = claim(q_head(ring), q_tail(ring), 1u, A.claim_k, &in_h);
+                if (in_n) { if (STATS) st_misc[ST_ENTRIES - ST_IDLE]++; return best_q; }
+                if (STATS) st_misc[ST_CLAIMFAIL - ST_IDLE]++;
+            }
+            if (primary_left && free_chunks >= (int)A.reserve_chunks) return Q_PRIMARY;
+            // nothing to do: whatever this wave still holds may be what the others are waiting for
+            if (flush_outs(true)) continue;
+            if (done_local) { if (lane_id() == 0) add_agent(ctl(C_DONE), done_local); done_local = 0u; }
+            if (uni(ld_agent(ctl(C_DONE))) >= A.n_items) return Q_EXIT;
+            if (STATS) st_misc[0]++;
+            // nothing will be started any more and this wave is not one of the closers: make room for the next launch's waves
+            if (!primary_left && blockIdx.x >= A.closers && idle >= 32u) return Q_EXIT;
+            if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
+            if (idle < 16u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
+    // ---- a loop stage: persistent lanes.  A lane takes a record, runs the stage's loop on it one step per trip of the wave loop,
+    // keeps the finished record until the wave's next service; a service pushes the finished records and refills the idle lanes
+    // from the input chunk (the next chunks of the queue as needed).  When the queue is dry the wave keeps stepping what it has,
+    // looks again every few trips while it is still reasonably full, and returns to the scheduler when its last lane has finished.
+    template <int Q, int SERVICE, typename Stage, int... TARGETS>
+    DE_DEV void run_loop(Stage& st, Targets<TARGETS...>) {
+        Path p;
+        bool busy = false, fin = false;
+        int target = -1;
+        bool dry = false;
+        uint32_t trips = 0, retry_at = 0, services = 0;
+        for (;;) {
+            const int nb = __popcll(__ballot(busy));
+            const bool may_refill = !dry || (nb >= 16 && trips >= retry_at);
+            if (nb == 0 || (64 - nb >= SERVICE && (may_refill || __ballot(fin) != 0ull))) {
+                ensure_stash();
+                (push<TARGETS>(p, fin && target == TARGETS), ...);
+                fin = false;
+                if (may_refill || nb == 0) {
+                    dry = false;
+                    bool got = false;
+                    uint32_t idx = 0;
+                    for (;;) {
+                        const unsigned long long m_need = __ballot(!busy && !got);
+                        if (m_need == 0ull) break;
+                        const uint32_t avail = in_hi - in_lo;
+                        if (avail == 0u) {
+                            if (!next_input()) { dry = true; retry_at = trips + 24u; break; }
+                            continue;
+                        }
+                        const uint32_t my = (uint32_t)__popcll(m_need & ((1ull << lane_id()) - 1ull));
+                        if (!busy && !got && my < avail) { idx = in_chunk * DE_V5_CH + in_lo + my; got = true; }
+                        const uint32_t take = min((uint32_t)__popcll(m_need), avail);
+                        in_lo += take;
+                        if (STATS) st_recs[Q] += take;
+                    }
+                    if (got) { load_rec(rs, idx, p); st.begin(p); busy = true; }
+                }
+                if (__ballot(busy) == 0ull) { if (dry || aborted) break; else continue; }
+                if ((++services & 31u) == 0u) flush_outs(false);
+            }
+            if (busy) {
+                if (st.step(p)) { target = st.finish(p); busy = false; fin = true; }
+            }
+            trips++;
+        }
+        leave_input();
+    }
+
+    // ---- a straight-line stage: one record per lane, chunk after chunk
+    template <int Q, typename Body, int... TARGETS>
+    DE_DEV void run_flat(Body body, Targets<TARGETS...>) {
+        for (;;) {
+            if (in_lo == in_hi && !next_input()) break;
+            ensure_stash();
+            const uint32_t n = in_hi - in_lo;
+            const bool active = (uint32_t)lane_id() < n;
+            Path p;
+            int target = -2;
+            if (active) { load_rec(rs, in_chunk * DE_V5_CH + in_lo + (uint32_t)lane_id(), p); target = body(p); }
+            in_lo += n;
+            if (STATS) st_recs[Q] += n;
+            done_local += (uint32_t)__popcll(__ballot(target == -1));
+            (push<TARGETS>(p, target == TARGETS), ...);
+        }
+        leave_input();
+    }
+
+    // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
+    DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
+        uint32_t w0 = 0;
+        if (lane_id() == 0) w0 = add_agent(ctl(C_WORK), 64u);
+        w0 = uni(w0);
+        if (w0 >= A.n_items) { primary_left = false; return; }
+        ensure_stash();
+        const uint32_t w = w0 + (uint32_t)lane_id();
+        const bool active = w < A.n_items;
+        const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+        Path p;
+        int target = -2;
+        if (active) {
+            wf::new_path(a, fc, s_node_val, w, p);
+            const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
+            target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
+        }
+        if (STATS) st_recs[NQ] += min(64u, A.n_items - w0);
+        push<Q_GAS>(p, target == Q_GAS);
+        push<Q_CLOUD>(p, target == Q_CLOUD);
+        push<Q_EVENT>(p, target == Q_EVENT);
+    }
+};
+
+}  // namespace ps
+
+#ifndef DE_V5_MIN_WAVES
+#define DE_V5_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (128 VGPRs)
+#endif
+#ifndef DE_V5_SVC_ST
+#define DE_V5_SVC_ST 32
+#endif
+#ifndef DE_V5_SVC_GAS
+#define DE_V5_SVC_GAS 32
+#endif
+#ifndef DE_V5_SVC_CLOUD
+#define DE_V5_SVC_CLOUD 12
+#endif
+
+// zero the control words, hand every chunk to the free ring (the queue rings are all-EMPTY: set by the host before the launch), and
+// put the launch's RenderArgs where the persistent kernel reads them
+__global__ void v5_init_kernel(uint32_t* ctl, uint32_t* free_ring, uint32_t pool_chunks, RenderArgs a, RenderArgs* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)ps::C_WORDS) ctl[i * DE_V5_CTL_STRIDE] = (i == (uint32_t)ps::C_FREE_TAIL) ? pool_chunks : 0u;
+    if (i < pool_chunks) free_ring[i] = i;
+    if (i == 0u) *dst = a;
+}
+
+// a pointer the optimiser knows nothing about: loads through it are neither hoisted above this point nor merged with earlier ones
+template <typename T> DE_DEV const T* v5_opaque(const T* p) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const T*>((uintptr_t)lo | ((uintptr_t)hi << 32));
+}
+
+template <bool CLAMP, bool STATS>
+__global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, const FrameConsts* fcp) {
+    using namespace ps;
+    __shared__ float s_node_val[64];
+    s_node_val[threadIdx.x & 63u] = A.ra->node_val[threadIdx.x & 63u];
+    __syncthreads();
+    Wave<CLAMP, STATS> W{A, s_node_val};
+    W.rs = __builtin_amdgcn_make_buffer_rsrc(A.pool, 0, (int)(A.pool_chunks * DE_V5_CH * 64u), 0x00020000);
+    {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        W.shard = (A.n_shards == 8u) ? (xcc & 7u) : (blockIdx.x % A.n_shards);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { W.oc[q] = DE_V5_NONE; W.of[q] = 0u; W.oa[q] = 0u; }
+    W.stash = 0u; W.n_stash = 0u;
+    W.in_ring = 0u; W.in_chunk = DE_V5_NONE; W.in_lo = W.in_hi = W.in_h = W.in_n = 0u;
+    W.done_local = 0u; W.primary_left = true; W.aborted = false;
+#pragma unroll
+    for (int q = 0; q <= NQ; ++q) { W.st_recs[q] = 0u; W.st_cyc[q] = 0ull; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W.st_misc[k] = 0u;
+    W.st_sched = 0ull; W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const ColdWT cold{A.cold};
+    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+
+    for (;;) {
+        const int s = W.schedule();
+        W.mark(-1);
+        if (s == Q_EXIT) break;
+        const RenderArgs& a = *v5_opaque(A.ra);
+        const FrameConsts& fc = *v5_opaque(fcp);
+        switch (s) {
+        case Q_ST: {
+            StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+            W.template run_loop<Q_ST, DE_V5_SVC_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+        } break;
+        case Q_GAS: {
+            GasStage st{a.nodes, a.dens_table};
+            W.template run_loop<Q_GAS, DE_V5_SVC_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+        } break;
+        case Q_CLOUD: {
+            CloudStage<CLAMP> st{a.clouds};
+            W.template run_loop<Q_CLOUD, DE_V5_SVC_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+        } break;
+        case Q_EVENT:
+            W.template run_flat<Q_EVENT>([&](Path& p) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
+            break;
+        case Q_SURF:
+            W.template run_flat<Q_SURF>([&](Path& p) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
+            break;
+        case Q_SCFIN:
+            W.template run_flat<Q_SCFIN>([&](Path& p) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
+            break;
+        case Q_SURFFIN:
+            W.template run_flat<Q_SURFFIN>([&](Path& p) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
+            break;
+        default:
+            W.run_primary(a, fc);
+            break;
+        }
+        W.mark(s);
+    }
+    if (STATS && lane_id() == 0) {
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) {
+            if (W.st_recs[q]) add_agent(A.ctl + (C_STAT0 + ST_RECS + q) * DE_V5_CTL_STRIDE, W.st_recs[q]);
+            add_agent(A.ctl + (C_STAT0 + ST_CYC + q) * DE_V5_CTL_STRIDE, (uint32_t)(W.st_cyc[q] >> 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (W.st_misc[k]) add_agent(A.ctl + (C_STAT0 + ST_IDLE + k) * DE_V5_CTL_STRIDE, W.st_misc[k]);
+        add_agent(A.ctl + (C_STAT0 + ST_SCHED_CYC) * DE_V5_CTL_STRIDE, (uint32_t)(W.st_sched >> 4));
+    }
+}

@@ -382,6 +382,12 @@ class Renderer:
         loops.  Identical results, bit for bit."""
         check(self._lib.de_set_kernel_variant(self._h, int(variant)))
 
+    def v5_stats(self, n=24):
+        """Statistics block of the persistent stage scheduler (kernel variant 5 with DE_V5_STATS=1); include/digital_earth.h."""
+        out = (ctypes.c_uint64 * n)()
+        check(self._lib.de_debug_v5_stats(self._h, out, n))
+        return [int(x) for x in out]
+
     def counters(self):
         c = DeCounters()
         check(self._lib.de_get_counters(self._h, ctypes.byref(c)))

@@ -230,6 +230,11 @@ int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
  * out[0..31] = lane / run counts per section, out[32..43] = shader cycles per section; n <= 48.  Index meaning:
  * tools/sched_stats.py.  Profiling aid only. */
 int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
+/* Statistics block of the persistent stage scheduler (kernel variant 5, environment DE_V5_STATS=1), summed over the launch slots'
+ * last launches; n <= 24: [0..7] records taken per stage (sphere trace, gas, cloud, event, surface, volume finish, surface finish,
+ * new paths), [8..15] wave-time per stage in 160 ns units, [16] idle scheduler rounds, [17] partial chunks published, [18] failed
+ * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler.  Profiling aid. */
+int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 
 const char* de_last_error(void);
