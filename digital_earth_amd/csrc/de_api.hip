@@ -266,9 +266,11 @@ struct de_ctx {
         uint32_t pool_chunks = 0, ring_cells = 0, n_shards = 0;
     } v5s[DE_MAX_SLOTS];
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
-    int v5_shards = 1;               // queue sets (1, or 8 = one per XCD; env DE_V5_SHARDS)
+    int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
+    int v5_local = 0;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
+    int v5_backlog = 8;              // chunks per wave queued in a shard before the waves stop starting new paths (env DE_V5_BACKLOG)
     int v5_pool_log2 = 18;           // chunks of 64 records in a slot's pool (2^18 = 1 GB; env DE_V5_POOL_LOG2)
-    int v5_claim_k = 2, v5_age = 20000, v5_closers_per_cu = 2, v5_stats = 0;   // env DE_V5_CLAIM_K / _AGE (10 ns ticks) / _CLOSERS / _STATS
+    int v5_claim_k = 16, v5_age = 20000, v5_closers_per_cu = 2, v5_stats = 0;   // env DE_V5_CLAIM_K / _AGE (10 ns ticks) / _CLOSERS / _STATS
     int v5_reserve_pct = 25;         // new paths start only while this share of the pool is free (env DE_V5_RESERVE_PCT)
     size_t v5_max_items = (size_t)1 << 27;   // paths per launch (64 B of cold record each; env DE_V5_MAX_ITEMS)
     int v5_batches = 1;              // launches a large call is cut into (they overlap on the launch slots; env DE_V5_BATCHES)
@@ -569,7 +571,8 @@ int v5_reserve(de_ctx* c, int si, size_t n_items) {
         HIP_TRY(hipStreamSynchronize(c->slot[si].stream));
         if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
         S.pool = nullptr; S.ctl = nullptr; S.rings = nullptr; S.free_ring = nullptr;
-        S.pool_chunks = pool_chunks; S.ring_cells = pool_chunks; S.n_shards = (uint32_t)c->v5_shards;
+        S.pool_chunks = pool_chunks; S.n_shards = (uint32_t)c->v5_shards;
+        S.ring_cells = pool_chunks;
         HIP_TRY(hipMalloc(&S.pool, (size_t)pool_chunks * DE_V5_CH * 64u));
         HIP_TRY(hipMalloc(&S.ctl, (size_t)ps::C_WORDS * DE_V5_CTL_STRIDE * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&S.rings, (size_t)S.n_shards * wf::NQ * S.ring_cells * sizeof(uint32_t)));
@@ -602,6 +605,7 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si)
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
     A.pool_chunks = S.pool_chunks; A.ring_mask = S.ring_cells - 1u; A.n_shards = S.n_shards;
     A.reserve_chunks = (uint32_t)((unsigned long long)S.pool_chunks * (unsigned)c->v5_reserve_pct / 100ull);
+    A.backlog_target = (uint32_t)((unsigned long long)c->n_cus * (unsigned)c->v5_wpc * (unsigned)c->v5_backlog / S.n_shards);
     A.claim_k = (uint32_t)c->v5_claim_k; A.age_max = (uint32_t)c->v5_age;
     A.closers = (uint32_t)(c->n_cus * c->v5_closers_per_cu);
     A.idle_limit = 1u << 20;
@@ -613,10 +617,15 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si)
     const unsigned by_work = (unsigned)((A.n_items + 63u) / 64u);
     const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v5_wpc;
     dim3 grid(by_work < machine ? (by_work ? by_work : 1u) : machine), block(64);
-    if (c->v5_stats) {
-        if (clamp) hipLaunchKernelGGL((v5_kernel<true, true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, true>), grid, block, 0, stream, A, a.fc);
+    // LOCAL: one queue set per XCD, a path lives and dies on the XCD that started it — records and cold records are handed over through
+    // that XCD's L2 with write-back stores.  Fewer shards (tests, experiments): any wave may take any chunk, everything is written through.
+    const bool local = c->v5_local && (S.n_shards % 8u) == 0u;
+    if (c->v5_stats && !clamp) {
+        if (local) hipLaunchKernelGGL((v5_kernel<false, true, true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, true, false>), grid, block, 0, stream, A, a.fc);
+    } else if (clamp) {
+        if (local) hipLaunchKernelGGL((v5_kernel<true, false, true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<true, false, false>), grid, block, 0, stream, A, a.fc);
     } else {
-        if (clamp) hipLaunchKernelGGL((v5_kernel<true, false>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, false>), grid, block, 0, stream, A, a.fc);
+        if (local) hipLaunchKernelGGL((v5_kernel<false, false, true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v5_kernel<false, false, false>), grid, block, 0, stream, A, a.fc);
     }
     return hipGetLastError();
 }
@@ -627,7 +636,7 @@ int check_v5_status(de_ctx* c) {
         if (S.h_status && S.h_status[0] != 0u) {
             const uint32_t code = S.h_status[0];
             S.h_status[0] = 0u;
-            return fail(DE_ERR_HIP, std::string("render_kernel_v5 left on its abort word (") + (code == ps::ERR_CELL_TIMEOUT ? "a ring cell was never stored" : code == ps::ERR_POOL_EMPTY ? "the chunk pool ran empty: raise DE_V5_POOL_LOG2" : "idle watchdog: work was lost") + "): the frame is invalid");
+            return fail(DE_ERR_HIP, std::string("render_kernel_v5 left on its abort word (") + (code == ps::ERR_CELL_TIMEOUT ? "a ring cell was never stored" : code == ps::ERR_POOL_EMPTY ? "the chunk pool ran empty: raise DE_V5_POOL_LOG2" : code == ps::ERR_RING_FULL ? "a queue ring wrapped: fewer shards or a lower DE_V5_BACKLOG" : "idle watchdog: work was lost") + "): the frame is invalid");
         }
     }
     return DE_OK;
@@ -809,11 +818,11 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
         env_int("DE_V5_WPC", &c->v5_wpc, 1); env_int("DE_V5_SHARDS", &c->v5_shards, 1); env_int("DE_V5_POOL_LOG2", &c->v5_pool_log2, 10);
         env_int("DE_V5_CLAIM_K", &c->v5_claim_k, 1); env_int("DE_V5_AGE", &c->v5_age, 1); env_int("DE_V5_CLOSERS", &c->v5_closers_per_cu, 1);
-        env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
+        env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
         if (const char* e7 = getenv("DE_V5_MAX_ITEMS")) { long long x = atoll(e7); if (x >= 4096) c->v5_max_items = (size_t)x; }
-        if (c->v5_shards != 8) c->v5_shards = c->v5_shards > 8 ? 8 : c->v5_shards;
+        if (c->v5_shards > 32) c->v5_shards = 32;            // every ring has a cell per chunk of the pool (it cannot wrap): 1 MB x 7 per shard
         if (c->v5_pool_log2 > 19) c->v5_pool_log2 = 19;      // 2^19 chunks x 4 KB = 2 GB: the buffer descriptor addresses < 4 GB
-        if (c->v5_claim_k > 4) c->v5_claim_k = 4;
+        if (c->v5_claim_k > 64) c->v5_claim_k = 64;
         if (c->v5_wpc > 32) c->v5_wpc = 32;
         c->v3_slack_wpc = c->v3_wpc > c->auto_wpc ? c->v3_wpc : c->auto_wpc;
         for (int i = 0; i < 4; ++i) if (c->v3_wpc_class[i] > c->v3_slack_wpc) c->v3_slack_wpc = c->v3_wpc_class[i];
@@ -1541,7 +1550,7 @@ int de_debug_v5_stats(de_ctx* c, uint64_t* out, int n) {
     for (auto& S : c->v5s) {
         if (!S.ctl) continue;
         HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int k = 0; k < n && k < ps::ST_N; ++k) out[k] += h[(size_t)(ps::C_STAT0 + k) * DE_V5_CTL_STRIDE];
+        for (int k = 0; k < n && k < ps::ST_N; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(ps::C_STAT0 + k) * DE_V5_CTL_STRIDE], 8); out[k] += v; }
     }
     return DE_OK;
 }

@@ -33,13 +33,13 @@ enum { Q_PRIMARY = NQ, Q_EXIT = NQ + 1 };
 #define DE_V5_EMPTY 0xffffffffu
 #define DE_V5_NONE 0xffffffffu
 #define DE_V5_CTL_STRIDE 32u               // one control word per 128-byte line
-#define DE_V5_MAX_SHARDS 8
+#define DE_V5_MAX_SHARDS 256
 // control words (index x DE_V5_CTL_STRIDE dwords)
-enum { C_WORK = 0, C_DONE = 1, C_ABORT = 2, C_FREE_HEAD = 3, C_FREE_TAIL = 4, C_STAT0 = 8, C_QUEUE0 = 40, C_WORDS = C_QUEUE0 + 2 * NQ * DE_V5_MAX_SHARDS };
+enum { C_WORK = 0, C_DONE = 1, C_ABORT = 2, C_FREE_HEAD = 3, C_FREE_TAIL = 4, C_STAT0 = 8, C_QUEUE0 = 56, C_WORDS = C_QUEUE0 + 2 * NQ * DE_V5_MAX_SHARDS };
 // statistics (C_STAT0 + k): 0-7 records taken per stage (7 = primary), 8-15 wave-cycles (s_memtime / 64) per stage, 16 idle loops,
 // 17 partial chunks published, 18 failed claims, 19 stage entries, 20 chunk allocations from the global ring, 21 steals
-enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_PARTIAL = 17, ST_CLAIMFAIL = 18, ST_ENTRIES = 19, ST_GALLOC = 20, ST_STEAL = 21, ST_SCHED_CYC = 22, ST_N = 24 };
-enum { ERR_CELL_TIMEOUT = 1, ERR_POOL_EMPTY = 2, ERR_IDLE_WATCHDOG = 3 };
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_PARTIAL = 17, ST_CLAIMFAIL = 18, ST_ENTRIES = 19, ST_GALLOC = 20, ST_STEAL = 21, ST_SCHED_CYC = 22, ST_T_INPUT = 23, ST_T_PUSH = 24, ST_T_SERVICE = 25, ST_T_BODY = 26, ST_T_ENSURE = 27, ST_T_FLUSH = 28, ST_T_SNAP = 29, ST_T_CLAIM = 30, ST_TRIPS = 32, ST_LANETRIPS = 35, ST_DRY = 38, ST_N = 40 };
+enum { ERR_CELL_TIMEOUT = 1, ERR_POOL_EMPTY = 2, ERR_IDLE_WATCHDOG = 3, ERR_RING_FULL = 4 };
 
 struct Args {
     const RenderArgs* ra;       // the launch's RenderArgs in device memory (written by v5_init_kernel): each stage reads what it needs
@@ -52,6 +52,8 @@ struct Args {
     uint32_t* status;           // host-visible: [0] abort code (0 = clean)
     uint32_t n_items, pool_chunks, ring_mask, n_shards;
     uint32_t reserve_chunks;    // new paths are started only while at least this many chunks are free
+    uint32_t backlog_target;    // ... and while fewer than this many chunks are queued in the wave's shard: deep queues keep the waves
+                                // in their stages (no scheduler round trips, full chunks), a bounded population keeps them in the caches
     uint32_t claim_k;           // chunks per claim (1..4)
     uint32_t age_max;           // a partial output chunk is published once it is this old (ticks of the 100 MHz constant clock)
     uint32_t closers;           // workgroups that stay until the last path has ended; the others leave when they run out of work
@@ -67,39 +69,51 @@ DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlan
 DE_DEV uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DE_DEV void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DE_DEV uint32_t add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DE_DEV void add_stat(uint32_t* p, unsigned long long v) { __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// records: four 16-byte sc1 accesses through a buffer descriptor over the pool (<= 4 GB)
+// records: four 16-byte sc1 accesses through a buffer descriptor over the pool (<= 4 GB).  A chunk is laid out QUAD-MAJOR — the first
+// 16 bytes of its 64 records, then the second 16 bytes of each, ... (4 x 1 KB) — so that each of the four instructions of a wave that
+// loads or stores consecutive records touches one contiguous run of bytes: whole 128-byte lines, each moved once.  (Record-major,
+// every instruction touched all 32 lines of the chunk: 4x the L2 requests and 16-byte partial write-throughs, measured 1.4 TB of
+// L2-miss traffic per frame.)
+DE_DEV int rec_offset(uint32_t rec) { return (int)((rec >> 6) * (DE_V5_CH * 64u) + (rec & 63u) * 16u); }
 DE_DEV void load_rec(__amdgpu_buffer_rsrc_t rs, uint32_t rec, Path& p) {
-    const int off = (int)(rec * 64u);
+    const int off = rec_offset(rec);
     const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, DE_V5_SC1);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, DE_V5_SC1);
-    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, DE_V5_SC1);
-    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 48, 0, DE_V5_SC1);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, DE_V5_SC1);
+    const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 2048, 0, DE_V5_SC1);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 3072, 0, DE_V5_SC1);
     p.pid = a.x; p.meta = a.y; p.rng.s0 = a.z; p.rng.s1 = a.w; p.rng.draws = 0;
     p.P = v3(wf::asf(b.x), wf::asf(b.y), wf::asf(b.z)); p.W = v3(wf::asf(b.w), wf::asf(c.x), wf::asf(c.y));
     p.x[0] = wf::asf(c.z); p.x[1] = wf::asf(c.w); p.x[2] = wf::asf(d.x); p.x[3] = wf::asf(d.y); p.x[4] = wf::asf(d.z); p.x[5] = wf::asf(d.w);
 }
+template <bool LOCAL>
 DE_DEV void store_rec(__amdgpu_buffer_rsrc_t rs, uint32_t rec, const Path& p) {
-    const int off = (int)(rec * 64u);
+    constexpr int AUX = LOCAL ? 0 : DE_V5_SC1;      // LOCAL: producer and consumer share an XCD's L2 (a write-back store reaches it; the consumer's sc1 load bypasses its L1)
+    const int off = rec_offset(rec);
     u32x4 a, b, c, d;
     a.x = p.pid; a.y = p.meta; a.z = p.rng.s0; a.w = p.rng.s1;
     b.x = wf::asu(p.P.x); b.y = wf::asu(p.P.y); b.z = wf::asu(p.P.z); b.w = wf::asu(p.W.x);
     c.x = wf::asu(p.W.y); c.y = wf::asu(p.W.z); c.z = wf::asu(p.x[0]); c.w = wf::asu(p.x[1]);
     d.x = wf::asu(p.x[2]); d.y = wf::asu(p.x[3]); d.z = wf::asu(p.x[4]); d.w = wf::asu(p.x[5]);
-    __builtin_amdgcn_raw_buffer_store_b128(a, rs, off, 0, DE_V5_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(b, rs, off + 16, 0, DE_V5_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(c, rs, off + 32, 0, DE_V5_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(d, rs, off + 48, 0, DE_V5_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(a, rs, off, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(b, rs, off + 1024, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(c, rs, off + 2048, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, off + 3072, 0, AUX);
 }
 
 // cold records: 8-byte agent-scope (sc1) accesses, any buffer size.  Layout (8-byte words): 0 (thr, Ls), 1 (dx, dy), 2 (dz, -),
 // 3 (nx, ny), 4 (nz, alb), 5 (ocean, bathy).  A path's cold record is written by the wave that then queues the path's record
 // (drained before the chunk is published) and read by the wave that claimed it: ordered by the chunk hand-over.
+template <bool LOCAL>
 struct ColdWT {
     unsigned long long* base;
     DE_DEV static unsigned long long pack(float a, float b) { return (unsigned long long)wf::asu(a) | ((unsigned long long)wf::asu(b) << 32); }
     DE_DEV unsigned long long ld(uint32_t pid, int k) const { return __hip_atomic_load(base + (size_t)pid * 8u + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    DE_DEV void st(uint32_t pid, int k, unsigned long long v) const { __hip_atomic_store(base + (size_t)pid * 8u + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    DE_DEV void st(uint32_t pid, int k, unsigned long long v) const {
+        if (LOCAL) base[(size_t)pid * 8u + k] = v;
+        else __hip_atomic_store(base + (size_t)pid * 8u + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     DE_DEV void get_thr_ls(uint32_t pid, float& thr, float& Ls) const { const unsigned long long v = ld(pid, 0); thr = wf::asf((uint32_t)v); Ls = wf::asf((uint32_t)(v >> 32)); }
     DE_DEV float get_ls(uint32_t pid) const { return wf::asf((uint32_t)(ld(pid, 0) >> 32)); }
     DE_DEV void set_thr_ls(uint32_t pid, float thr, float Ls) const { st(pid, 0, pack(thr, Ls)); }
@@ -119,7 +133,7 @@ struct ColdWT {
 };
 
 // Everything a wave carries between stages.  All members are wave-uniform (SGPRs) except `stash`: lane i holds free chunk id i.
-template <bool CLAMP, bool STATS>
+template <bool CLAMP, bool STATS, bool LOCAL>
 struct Wave {
     const Args& A;
     const float* s_node_val;
@@ -132,11 +146,15 @@ struct Wave {
     // input side: the queue being drained
     uint32_t in_ring;           // index of the ring ((shard x NQ + q), possibly another shard's when stealing)
     uint32_t in_chunk, in_lo, in_hi, in_h, in_n;
+    uint32_t in_cells, in_k;    // the cells of the current claim as first read (lane j = cell j; DE_V5_EMPTY = not yet stored), entries read so far
     uint32_t done_local;
+    uint32_t w_lo, w_hi;        // work items (new paths) this wave has drawn from the device-wide counter
+    uint32_t victim;            // the other team this wave looks at next when its own has nothing
     bool primary_left, aborted;
     // statistics
     uint32_t st_recs[NQ + 1], st_misc[8];
-    unsigned long long st_cyc[NQ + 1], st_sched, t_mark;
+    unsigned long long st_cyc[NQ + 1], st_sched, t_mark, st_t[8], st_trips[3], st_lanes[3];
+    uint32_t st_dry;
 
     DE_DEV uint32_t* ctl(uint32_t k) const { return A.ctl + k * DE_V5_CTL_STRIDE; }
     DE_DEV uint32_t* q_head(uint32_t ring) const { return ctl(C_QUEUE0 + 2u * ring); }
@@ -193,31 +211,29 @@ struct Wave {
     // i.e. between any two of its calls at most eight chunks are taken — is the only place that goes to the device-wide ring for more.
     DE_DEV void ensure_stash() {
         if (n_stash >= 8u) return;
-        uint32_t first = 0, k = 0;
-#pragma nounroll
-        for (uint32_t spins = 0; spins < (1u << 16) && !abort_seen(); ++spins) {
-            k = claim(ctl(C_FREE_HEAD), ctl(C_FREE_TAIL), 8u, 8u, &first);
-            if (k) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!k) { if (!aborted) raise(ERR_POOL_EMPTY); return; }
+        // eight tickets of the free ring with ONE fetch-add (thousands of waves on a compare-and-swap retry each other quadratically:
+        // measured 27 % of all wave-time at 16 waves per CU); a ticket past the tail waits for a chunk to come back — the pool is sized
+        // so that this does not happen, and the wait is bounded
+        uint32_t first = 0;
+        if (lane_id() == 0) first = add_agent(ctl(C_FREE_HEAD), 8u);
+        first = uni(first);
         if (STATS) st_misc[ST_GALLOC - ST_IDLE]++;
         const uint32_t l = (uint32_t)lane_id();
         uint32_t c = 0u;
-        if (l >= n_stash && l < n_stash + k) {
+        if (l >= n_stash && l < n_stash + 8u) {
             uint32_t* cell = A.free_ring + ((first + (l - n_stash)) & (A.pool_chunks - 1u));
             c = DE_V5_EMPTY;
 #pragma nounroll
-            for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            for (uint32_t spins = 0; spins < (1u << 21); ++spins) {
                 c = ld_agent(cell);
                 if (c != DE_V5_EMPTY) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(4);
             }
             if (c != DE_V5_EMPTY) st_agent(cell, DE_V5_EMPTY);
             stash = c;
         }
-        if (__ballot(c == DE_V5_EMPTY) != 0ull) { raise(ERR_CELL_TIMEOUT); return; }
-        n_stash += k;
+        if (__ballot(c == DE_V5_EMPTY) != 0ull) { raise(ERR_POOL_EMPTY); n_stash += 8u; return; }
+        n_stash += 8u;
     }
     DE_DEV uint32_t alloc_chunk() {
         if (n_stash == 0u) { if (!aborted) raise(ERR_POOL_EMPTY); return 0u; }      // cannot happen (ensure_stash); chunk 0 is scribbled on and the frame reported as failed
@@ -227,24 +243,25 @@ struct Wave {
     DE_DEV void free_chunk(uint32_t chunk) {
         if ((uint32_t)lane_id() == n_stash) stash = chunk;
         n_stash++;
-        if (n_stash >= 40u) {           // give sixteen back
+        if (n_stash >= 24u) {           // give eight back
             uint32_t i = 0;
-            if (lane_id() == 0) i = add_agent(ctl(C_FREE_TAIL), 16u);
+            if (lane_id() == 0) i = add_agent(ctl(C_FREE_TAIL), 8u);
             i = uni(i);
             const uint32_t l = (uint32_t)lane_id();
-            if (l >= n_stash - 16u && l < n_stash) st_agent(A.free_ring + ((i + (l - (n_stash - 16u))) & (A.pool_chunks - 1u)), stash);
-            n_stash -= 16u;
+            if (l >= n_stash - 8u && l < n_stash) st_agent(A.free_ring + ((i + (l - (n_stash - 8u))) & (A.pool_chunks - 1u)), stash);
+            n_stash -= 8u;
         }
     }
 
     // ---- output side
     DE_DEV void publish(uint32_t q, uint32_t chunk, uint32_t count) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's record and cold stores have been written through
-        if (lane_id() == 0) {
-            const uint32_t ring = shard * NQ + q;
-            const uint32_t i = add_agent(q_tail(ring), 1u);
-            st_agent(ring_cells(ring) + (i & A.ring_mask), chunk * 128u + count);
-        }
+        // the ticket first: its round trip overlaps the drain of the record stores (a consumer that claims the ticket early waits for
+        // the cell, which is stored only after the drain)
+        const uint32_t ring = shard * NQ + q;
+        uint32_t i = 0;
+        if (lane_id() == 0) i = add_agent(q_tail(ring), 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's record and cold stores have reached the coherence point
+        if (lane_id() == 0) st_agent(ring_cells(ring) + (i & A.ring_mask), chunk * 128u + count);
     }
     template <int Q>
     DE_DEV void push(const Path& p, bool pred) {
@@ -253,12 +270,12 @@ struct Wave {
         const uint32_t n = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
         if (oc[Q] == DE_V5_NONE) { oc[Q] = alloc_chunk(); of[Q] = 0u; oa[Q] = now(); }
         const uint32_t rem = DE_V5_CH - of[Q];
-        if (pred && rank < rem) store_rec(rs, oc[Q] * DE_V5_CH + of[Q] + rank, p);
+        if (pred && rank < rem) store_rec<LOCAL>(rs, oc[Q] * DE_V5_CH + of[Q] + rank, p);
         if (n >= rem) {
             publish(Q, oc[Q], DE_V5_CH);
             if (n > rem) {
                 oc[Q] = alloc_chunk(); of[Q] = n - rem; oa[Q] = now();
-                if (pred && rank >= rem) store_rec(rs, oc[Q] * DE_V5_CH + (rank - rem), p);
+                if (pred && rank >= rem) store_rec<LOCAL>(rs, oc[Q] * DE_V5_CH + (rank - rem), p);
             } else { oc[Q] = DE_V5_NONE; of[Q] = 0u; }
         } else of[Q] += n;
     }
@@ -282,17 +299,34 @@ struct Wave {
 
     // ---- input side
     DE_DEV bool next_input() {
+        const unsigned long long t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        const bool r = next_input_();
+        if (STATS) st_t[0] += __builtin_amdgcn_s_memrealtime() - t0;
+        return r;
+    }
+    DE_DEV bool next_input_() {
         if (in_chunk != DE_V5_NONE) { free_chunk(in_chunk); in_chunk = DE_V5_NONE; }
         in_lo = in_hi = 0u;
         if (in_n == 0u) {
             in_n = claim(q_head(in_ring), q_tail(in_ring), 1u, A.claim_k, &in_h);
             if (in_n == 0u) return false;
+            fetch_cells();
         }
-        const uint32_t cell = take_cell(ring_cells(in_ring), A.ring_mask, in_h);
-        in_h++; in_n--;
+        uint32_t cell = (uint32_t)__builtin_amdgcn_readlane((int)in_cells, (int)in_k);
+        if (cell == DE_V5_EMPTY) cell = take_cell(ring_cells(in_ring), A.ring_mask, in_h);      // its producer had not stored it yet: wait for it
+        in_h++; in_n--; in_k++;
         if (cell == DE_V5_EMPTY) return false;
         in_chunk = cell >> 7; in_lo = 0u; in_hi = cell & 127u;
         return true;
+    }
+    // one round trip for all cells of a fresh claim (in_h .. in_h + in_n): lane j reads cell j and, if it is there, frees it
+    DE_DEV void fetch_cells() {
+        in_cells = DE_V5_EMPTY; in_k = 0u;
+        if ((uint32_t)lane_id() < in_n) {
+            uint32_t* cell = ring_cells(in_ring) + ((in_h + (uint32_t)lane_id()) & A.ring_mask);
+            in_cells = ld_agent(cell);
+            if (in_cells != DE_V5_EMPTY) st_agent(cell, DE_V5_EMPTY);
+        }
     }
     DE_DEV void leave_input() {
         if (in_chunk != DE_V5_NONE && in_lo == in_hi) { free_chunk(in_chunk); in_chunk = DE_V5_NONE; }
@@ -311,44 +345,61 @@ struct Wave {
         uint32_t idle = 0;
         for (;;) {
             if (abort_seen()) return Q_EXIT;
+            unsigned long long tq = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             flush_outs(false);
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[5] += t - tq; tq = t; }
             ensure_stash();
-            // one look at every queue: lane l reads head and tail of ring l; lanes 62 / 63 the work counter and the free-chunk count
-            const uint32_t n_rings = A.n_shards * NQ;
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[4] += t - tq; tq = t; }
+            // one look at this team's queues: lane q reads head and tail of ring (shard, q); lanes 62 / 63 the work counter and the
+            // free-chunk count.  (A team = the waves of one shard: an XCD in LOCAL mode, else the blocks with index = shard mod n_shards.)
             int ready = 0;
             const uint32_t l = (uint32_t)lane_id();
-            if (l < n_rings) { const uint32_t h = ld_agent(q_head(l)), t = ld_agent(q_tail(l)); ready = (int)(t - h); }
+            if (l < (uint32_t)NQ) { const uint32_t r = shard * NQ + l; const uint32_t h = ld_agent(q_head(r)), t = ld_agent(q_tail(r)); ready = (int)(t - h); }
             else if (l == 62u) ready = (int)ld_agent(ctl(C_WORK));
             else if (l == 63u) ready = (int)(ld_agent(ctl(C_FREE_TAIL)) - ld_agent(ctl(C_FREE_HEAD)));
             const uint32_t work_next = (uint32_t)__builtin_amdgcn_readlane(ready, 62);
             const int free_chunks = __builtin_amdgcn_readlane(ready, 63);
-            if (work_next >= A.n_items) primary_left = false;
-            // the fullest queue of this wave's shard; another shard's when its own has nothing
-            int best_q = -1, best = 0;
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[6] += t - tq; tq = t; }
+            if (work_next >= A.n_items && w_lo >= w_hi) primary_left = false;
+            // the fullest queue, and how much is queued in all
+            int best_q = -1, best = 0, backlog = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int r = __builtin_amdgcn_readlane(ready, (int)(shard * NQ) + q);
+                const int r = __builtin_amdgcn_readlane(ready, q);
+                if (r > 0) backlog += r;
                 if (r > best) { best = r; best_q = q; }
             }
+            const bool may_start = primary_left && free_chunks >= (int)A.reserve_chunks;
+            // shallow queues: start new paths rather than fight over the few chunks there are
+            if (may_start && backlog < (int)A.backlog_target) return Q_PRIMARY;
             uint32_t ring = shard * NQ + (uint32_t)(best_q < 0 ? 0 : best_q);
-            if (best_q < 0 && A.n_shards > 1u) {
-                const unsigned long long m = __ballot(l < n_rings && ready > 0);
-                if (m != 0ull) {
-                    // start looking after this wave's own rings so that the thieves spread over the victims
-                    const uint32_t rot = (shard * NQ + NQ) & 63u;
-                    const unsigned long long mr = (m >> rot) | (rot ? (m << (64u - rot)) : 0ull);
-                    ring = ((uint32_t)__builtin_ctzll(mr) + rot) & 63u;
-                    best_q = (int)(ring % NQ);
-                    if (STATS) st_misc[ST_STEAL - ST_IDLE]++;
+            if (best_q < 0 && !may_start && A.n_shards > (LOCAL ? 8u : 1u)) {
+                // nothing here and nothing to start: look at one other team (LOCAL: one of the same XCD — a path never leaves its XCD)
+                if (LOCAL) {
+                    const uint32_t per_xcd = A.n_shards >> 3, base = shard - shard % per_xcd;
+                    victim = victim + 1u >= base + per_xcd ? base : victim + 1u;
+                    if (victim == shard) victim = victim + 1u >= base + per_xcd ? base : victim + 1u;
+                } else {
+                    victim = victim + 1u >= A.n_shards ? 0u : victim + 1u;
+                    if (victim == shard) victim = victim + 1u >= A.n_shards ? 0u : victim + 1u;
                 }
+                int vr = 0;
+                if (l < (uint32_t)NQ) { const uint32_t r = victim * NQ + l; const uint32_t h = ld_agent(q_head(r)), t = ld_agent(q_tail(r)); vr = (int)(t - h); }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int r = __builtin_amdgcn_readlane(vr, q);
+                    if (r > best) { best = r; best_q = q; }
+                }
+                if (best_q >= 0) { ring = victim * NQ + (uint32_t)best_q; if (STATS) st_misc[ST_STEAL - ST_IDLE]++; }
             }
             if (best_q >= 0) {
                 in_ring = ring;
                 in_n = claim(q_head(ring), q_tail(ring), 1u, A.claim_k, &in_h);
-                if (in_n) { if (STATS) st_misc[ST_ENTRIES - ST_IDLE]++; return best_q; }
+                if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[7] += t - tq; tq = t; }
+                if (in_n) { fetch_cells(); if (STATS) st_misc[ST_ENTRIES - ST_IDLE]++; return best_q; }
                 if (STATS) st_misc[ST_CLAIMFAIL - ST_IDLE]++;
             }
-            if (primary_left && free_chunks >= (int)A.reserve_chunks) return Q_PRIMARY;
+            if (may_start) return Q_PRIMARY;
             // nothing to do: whatever this wave still holds may be what the others are waiting for
             if (flush_outs(true)) continue;
             if (done_local) { if (lane_id() == 0) add_agent(ctl(C_DONE), done_local); done_local = 0u; }
@@ -357,7 +408,10 @@ struct Wave {
             // nothing will be started any more and this wave is not one of the closers: make room for the next launch's waves
             if (!primary_left && blockIdx.x >= A.closers && idle >= 32u) return Q_EXIT;
             if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
-            if (idle < 16u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+            // back off: 0.2 us at first, ~25 us after a few hundred rounds (thousands of waves polling the same lines starve the producers)
+            { const uint32_t reps = idle < 8u ? 1u : (idle < 64u ? 4u : 32u);
+#pragma nounroll
+              for (uint32_t k = 0; k < reps; ++k) __builtin_amdgcn_s_sleep(32); }
         }
     }
 
@@ -376,9 +430,11 @@ struct Wave {
             const int nb = __popcll(__ballot(busy));
             const bool may_refill = !dry || (nb >= 16 && trips >= retry_at);
             if (nb == 0 || (64 - nb >= SERVICE && (may_refill || __ballot(fin) != 0ull))) {
+                const unsigned long long ts0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 ensure_stash();
                 (push<TARGETS>(p, fin && target == TARGETS), ...);
                 fin = false;
+                if (STATS) st_t[1] += __builtin_amdgcn_s_memrealtime() - ts0;
                 if (may_refill || nb == 0) {
                     dry = false;
                     bool got = false;
@@ -388,7 +444,7 @@ struct Wave {
                         if (m_need == 0ull) break;
                         const uint32_t avail = in_hi - in_lo;
                         if (avail == 0u) {
-                            if (!next_input()) { dry = true; retry_at = trips + 24u; break; }
+                            if (!next_input()) { dry = true; retry_at = trips + 24u; if (STATS) st_dry++; break; }
                             continue;
                         }
                         const uint32_t my = (uint32_t)__popcll(m_need & ((1ull << lane_id()) - 1ull));
@@ -399,9 +455,11 @@ struct Wave {
                     }
                     if (got) { load_rec(rs, idx, p); st.begin(p); busy = true; }
                 }
+                if (STATS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_t[2] += __builtin_amdgcn_s_memrealtime() - ts0; }
                 if (__ballot(busy) == 0ull) { if (dry || aborted) break; else continue; }
                 if ((++services & 31u) == 0u) flush_outs(false);
             }
+            if (STATS) { st_trips[Q] += 1ull; st_lanes[Q] += (unsigned long long)__popcll(__ballot(busy)); }
             if (busy) {
                 if (st.step(p)) { target = st.finish(p); busy = false; fin = true; }
             }
@@ -420,24 +478,33 @@ struct Wave {
             const bool active = (uint32_t)lane_id() < n;
             Path p;
             int target = -2;
+            const unsigned long long tb0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             if (active) { load_rec(rs, in_chunk * DE_V5_CH + in_lo + (uint32_t)lane_id(), p); target = body(p); }
+            if (STATS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_t[3] += __builtin_amdgcn_s_memrealtime() - tb0; }
             in_lo += n;
             if (STATS) st_recs[Q] += n;
             done_local += (uint32_t)__popcll(__ballot(target == -1));
+            const unsigned long long tp0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             (push<TARGETS>(p, target == TARGETS), ...);
+            if (STATS) st_t[1] += __builtin_amdgcn_s_memrealtime() - tp0;
         }
         leave_input();
     }
 
     // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
     DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
-        uint32_t w0 = 0;
-        if (lane_id() == 0) w0 = add_agent(ctl(C_WORK), 64u);
-        w0 = uni(w0);
-        if (w0 >= A.n_items) { primary_left = false; return; }
+        if (w_lo >= w_hi) {          // 256 work items per atomic: four passes
+            uint32_t w = 0;
+            if (lane_id() == 0) w = add_agent(ctl(C_WORK), 256u);
+            w = uni(w);
+            if (w >= A.n_items) { primary_left = false; return; }
+            w_lo = w; w_hi = min(w + 256u, A.n_items);
+        }
+        const uint32_t w0 = w_lo;
+        w_lo += 64u;
         ensure_stash();
         const uint32_t w = w0 + (uint32_t)lane_id();
-        const bool active = w < A.n_items;
+        const bool active = w < w_hi;
         const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
         Path p;
         int target = -2;
@@ -446,7 +513,7 @@ struct Wave {
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
         }
-        if (STATS) st_recs[NQ] += min(64u, A.n_items - w0);
+        if (STATS) st_recs[NQ] += min(64u, w_hi - w0);
         push<Q_GAS>(p, target == Q_GAS);
         push<Q_CLOUD>(p, target == Q_CLOUD);
         push<Q_EVENT>(p, target == Q_EVENT);
@@ -472,7 +539,7 @@ struct Wave {
 // put the launch's RenderArgs where the persistent kernel reads them
 __global__ void v5_init_kernel(uint32_t* ctl, uint32_t* free_ring, uint32_t pool_chunks, RenderArgs a, RenderArgs* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)ps::C_WORDS) ctl[i * DE_V5_CTL_STRIDE] = (i == (uint32_t)ps::C_FREE_TAIL) ? pool_chunks : 0u;
+    if (i < (uint32_t)ps::C_WORDS) { ctl[i * DE_V5_CTL_STRIDE] = (i == (uint32_t)ps::C_FREE_TAIL) ? pool_chunks : 0u; ctl[i * DE_V5_CTL_STRIDE + 1u] = 0u; }
     if (i < pool_chunks) free_ring[i] = i;
     if (i == 0u) *dst = a;
 }
@@ -484,30 +551,39 @@ template <typename T> DE_DEV const T* v5_opaque(const T* p) {
     return reinterpret_cast<const T*>((uintptr_t)lo | ((uintptr_t)hi << 32));
 }
 
-template <bool CLAMP, bool STATS>
+template <bool CLAMP, bool STATS, bool LOCAL>
 __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, const FrameConsts* fcp) {
     using namespace ps;
     __shared__ float s_node_val[64];
     s_node_val[threadIdx.x & 63u] = A.ra->node_val[threadIdx.x & 63u];
     __syncthreads();
-    Wave<CLAMP, STATS> W{A, s_node_val};
+    Wave<CLAMP, STATS, LOCAL> W{A, s_node_val};
     W.rs = __builtin_amdgcn_make_buffer_rsrc(A.pool, 0, (int)(A.pool_chunks * DE_V5_CH * 64u), 0x00020000);
     {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        W.shard = (A.n_shards == 8u) ? (xcc & 7u) : (blockIdx.x % A.n_shards);
+        // a team = the waves of one shard.  LOCAL: n_shards / 8 teams per XCD (block b runs on XCD b mod 8: the blocks of an XCD are dealt
+        // round robin to its teams; correctness only needs that a team's waves share the XCD, which the register says)
+        const uint32_t per_xcd = A.n_shards >> 3;
+        W.shard = LOCAL ? ((xcc & 7u) * per_xcd + (blockIdx.x >> 3) % per_xcd) : (blockIdx.x % A.n_shards);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { W.oc[q] = DE_V5_NONE; W.of[q] = 0u; W.oa[q] = 0u; }
     W.stash = 0u; W.n_stash = 0u;
-    W.in_ring = 0u; W.in_chunk = DE_V5_NONE; W.in_lo = W.in_hi = W.in_h = W.in_n = 0u;
+    W.in_ring = 0u; W.in_chunk = DE_V5_NONE; W.in_lo = W.in_hi = W.in_h = W.in_n = 0u; W.in_cells = DE_V5_EMPTY; W.in_k = 0u;
     W.done_local = 0u; W.primary_left = true; W.aborted = false;
+    W.w_lo = W.w_hi = 0u; W.victim = W.shard;
 #pragma unroll
     for (int q = 0; q <= NQ; ++q) { W.st_recs[q] = 0u; W.st_cyc[q] = 0ull; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) W.st_misc[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) W.st_t[k] = 0ull;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { W.st_trips[k] = 0ull; W.st_lanes[k] = 0ull; }
+    W.st_dry = 0u;
     W.st_sched = 0ull; W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const ColdWT cold{A.cold};
+    const ColdWT<LOCAL> cold{A.cold};
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
 
     for (;;) {
@@ -550,11 +626,16 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
     if (STATS && lane_id() == 0) {
 #pragma unroll
         for (int q = 0; q <= NQ; ++q) {
-            if (W.st_recs[q]) add_agent(A.ctl + (C_STAT0 + ST_RECS + q) * DE_V5_CTL_STRIDE, W.st_recs[q]);
-            add_agent(A.ctl + (C_STAT0 + ST_CYC + q) * DE_V5_CTL_STRIDE, (uint32_t)(W.st_cyc[q] >> 4));
+            if (W.st_recs[q]) add_stat(A.ctl + (C_STAT0 + ST_RECS + q) * DE_V5_CTL_STRIDE, W.st_recs[q]);
+            add_stat(A.ctl + (C_STAT0 + ST_CYC + q) * DE_V5_CTL_STRIDE, W.st_cyc[q]);
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) if (W.st_misc[k]) add_agent(A.ctl + (C_STAT0 + ST_IDLE + k) * DE_V5_CTL_STRIDE, W.st_misc[k]);
-        add_agent(A.ctl + (C_STAT0 + ST_SCHED_CYC) * DE_V5_CTL_STRIDE, (uint32_t)(W.st_sched >> 4));
+        for (int k = 0; k < 6; ++k) if (W.st_misc[k]) add_stat(A.ctl + (C_STAT0 + ST_IDLE + k) * DE_V5_CTL_STRIDE, W.st_misc[k]);
+        add_stat(A.ctl + (C_STAT0 + ST_SCHED_CYC) * DE_V5_CTL_STRIDE, W.st_sched);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) add_stat(A.ctl + (C_STAT0 + ST_T_INPUT + k) * DE_V5_CTL_STRIDE, W.st_t[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { add_stat(A.ctl + (C_STAT0 + ST_TRIPS + k) * DE_V5_CTL_STRIDE, W.st_trips[k]); add_stat(A.ctl + (C_STAT0 + ST_LANETRIPS + k) * DE_V5_CTL_STRIDE, W.st_lanes[k]); }
+        add_stat(A.ctl + (C_STAT0 + ST_DRY) * DE_V5_CTL_STRIDE, W.st_dry);
     }
 }

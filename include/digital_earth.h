@@ -231,9 +231,10 @@ int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
  * tools/sched_stats.py.  Profiling aid only. */
 int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
 /* Statistics block of the persistent stage scheduler (kernel variant 5, environment DE_V5_STATS=1), summed over the launch slots'
- * last launches; n <= 24: [0..7] records taken per stage (sphere trace, gas, cloud, event, surface, volume finish, surface finish,
- * new paths), [8..15] wave-time per stage in 160 ns units, [16] idle scheduler rounds, [17] partial chunks published, [18] failed
- * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler.  Profiling aid. */
+ * last launches; n <= 40: [0..7] records taken per stage (sphere trace, gas, cloud, event, surface, volume finish, surface finish,
+ * new paths), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] partial chunks published, [18] failed
+ * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler, [23] in next_input, [24] in pushes, [25] in loop-stage services, [26] in straight-line bodies, [27..30] of the scheduler's: free-chunk refill, age flush, queue snapshot, claim, [32..34] wave-trips of the three loop
+ * stages, [35..37] their lane-trips, [38] times a loop stage found its queue dry.  Profiling aid. */
 int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 

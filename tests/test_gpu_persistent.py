@@ -41,10 +41,10 @@ def test_persistent_scheduler_matches_the_oracle(Renderer, lut_arrays, preset):
     assert got.max() > 0
 
 
-@pytest.mark.parametrize("shards,pool_log2,claim_k,wpc", [(1, 18, 2, 16), (8, 18, 1, 16), (1, 12, 4, 4), (8, 13, 1, 8), (2, 18, 2, 20)])
+@pytest.mark.parametrize("shards,pool_log2,claim_k,wpc", [(1, 18, 2, 16), (8, 18, 1, 16), (1, 14, 4, 1), (8, 15, 1, 2), (2, 18, 2, 20)])
 def test_persistent_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, shards, pool_log2, claim_k, wpc):
-    """Queue shards (1 / one per XCD), a pool so small that every chunk is recycled hundreds of times (2^12 chunks = 256 K records for
-    a launch of 2.4 M paths on 1024 waves), chunk claims of 1..4, 4..20 waves per CU: the frame is the state machine's, bit for bit."""
+    """Queue shards (1 / one per XCD), a pool so small that every chunk is recycled hundreds of times (2^14 chunks for a launch of
+    1.6 M paths on 256 waves: each wave may hold ~24 chunks), chunk claims of 1..4, 4..20 waves per CU: the frame is the state machine's, bit for bit."""
     monkeypatch.setenv("DE_V5_SHARDS", str(shards)); monkeypatch.setenv("DE_V5_POOL_LOG2", str(pool_log2))
     monkeypatch.setenv("DE_V5_CLAIM_K", str(claim_k)); monkeypatch.setenv("DE_V5_WPC", str(wpc))
     monkeypatch.setenv("DE_V5_RESERVE_PCT", "50")

@@ -7,7 +7,7 @@ for l in open(sys.argv[1]):
         j=json.loads(l); print("value %.1f Msamples/s, %.1f ms/step, single frame %.1f ms" % (j["value"], j["ms_per_step"], j.get("single_frame_ms", float("nan"))))
 PY
 }
-for k in 4 2; do
+for k in ${DE_PRESET_KERNELS:-4 2}; do
   echo -n "DE_KERNEL=$k default camera : "; DE_KERNEL=$k python3 bench.py --no-cpu-baseline --steps 4 > /tmp/b.json 2>/tmp/b.err; line /tmp/b.json
   for p in "config - florida.txt" "config - sunset hurricane.txt" "config - Apollo 11.txt"; do
     echo -n "DE_KERNEL=$k $p : "; DE_KERNEL=$k python3 bench.py --no-cpu-baseline --steps 4 --preset "$p" > /tmp/b.json 2>/tmp/b.err; line /tmp/b.json

@@ -42,7 +42,7 @@ def print_stats(r, ms, n_waves):
         print("  %-14s %10d   %6.1f %%" % (name, st[k], 100.0 * st[8 + k] / max(tot, 1)))
     print("  %-14s %10s   %6.1f %%   (idle rounds %d, partial chunks %d, failed claims %d, stage entries %d, ring refills %d, steals %d)"
           % ("scheduler", "", 100.0 * st[22] / max(tot, 1), st[16], st[17], st[18], st[19], st[20], st[21]))
-    print("  wave-time total %.1f ms x waves (launch %.1f ms x %d waves = %.1f)" % (tot * 160e-6, ms, n_waves, ms * n_waves))
+    print("  wave-time total %.1f ms x waves (launch %.1f ms x %d waves = %.1f)" % (tot * 10e-6, ms, n_waves, ms * n_waves))
 
 
 ok = True
