@@ -111,6 +111,28 @@ DE_DEV uint32_t tap_r8_issue(const TexR8& t, float u, float v, float* fx_out, fl
     *fx_out = fx; *fy_out = fy;
     return t.data[idx];
 }
+// The same tap for a caller that samples the map at points a fraction of a texel apart (tracking through the cloud shell: a free
+// flight of ~345 m against texels of 1.85 km): the footprint dword of the previous tap is kept, and a tap whose footprint is the
+// same entry reuses it — same dword, same result, no load.
+template <bool CLAMP>
+DE_DEV uint32_t tap_r8_issue_cached(const TexR8& t, float u, float v, float* fx_out, float* fy_out, uint32_t& last_idx, uint32_t& last_q) {
+    float x = u * t.wf - 0.5f;
+    float y = v * t.hf - 0.5f;
+    float x0f = de_floor(x), y0f = de_floor(y);
+    float fx = x - x0f, fy = y - y0f;
+    int i0 = (int)x0f, j0 = (int)y0f;
+    if (CLAMP) {
+        if (i0 < 0) { i0 = 0; fx = 0.0f; }
+        if (j0 < 0) { j0 = 0; fy = 0.0f; }
+    } else {
+        if (i0 < 0) i0 = t.w - 1;
+        if (j0 < 0) j0 = t.h - 1;
+    }
+    const uint32_t idx = ((uint32_t)(j0 >> 2) * (uint32_t)t.tiles_x + (uint32_t)(i0 >> 3)) * 32u + (uint32_t)(((j0 & 3) << 3) | (i0 & 7));
+    *fx_out = fx; *fy_out = fy;
+    if (idx != last_idx) { last_q = t.data[idx]; last_idx = idx; }
+    return last_q;
+}
 DE_DEV float tap_r8_finish(uint32_t q, float fx, float fy) {
     // contract 2: the bilinear filter runs on the byte values (exact small integers), the result is scaled by RN(1/255)
     float t00 = (float)(q & 255u), t10 = (float)((q >> 8) & 255u), t01 = (float)((q >> 16) & 255u), t11 = (float)(q >> 24);

@@ -752,6 +752,9 @@ struct CloudStage {
     float ext_w, rmaxc, t, tmax, trn;
     vec3 C;
     int kind, cloud_event;
+#ifndef DE_NO_TAP_REUSE
+    uint32_t last_idx = 0xffffffffu, last_q = 0u;      // the lane's previous cloud-map footprint (de_device.h: tap_r8_issue_cached); outlives the record
+#endif
     DE_DEV void begin(wf::Path& p) {
         const int sc = wf::m_sc(p.meta);
         ext_w = (sc > 9) ? 0.02f : DE_CLOUDS_EXTINCT;
@@ -772,7 +775,13 @@ struct CloudStage {
         if (len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER) {
             const vec3 nrm = C * de_rcp_nr(len);
             const vec2_ uv = sphere_UV_map(nrm);
+#ifndef DE_NO_TAP_REUSE
+            float fx, fy;
+            const uint32_t q = tap_r8_issue_cached<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &fx, &fy, last_idx, last_q);
+            const float tex = tap_r8_finish(q, fx, fy);
+#else
             const float tex = tap_r8<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
+#endif
             const float h = (len - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
             const float split = 0.2f;
             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;

@@ -38,7 +38,7 @@ enum { Q_PRIMARY = NQ, Q_EXIT = NQ + 1 };
 enum { C_WORK = 0, C_DONE = 1, C_ABORT = 2, C_FREE_HEAD = 3, C_FREE_TAIL = 4, C_STAT0 = 8, C_QUEUE0 = 56, C_WORDS = C_QUEUE0 + 2 * NQ * DE_V5_MAX_SHARDS };
 // statistics (C_STAT0 + k): 0-7 records taken per stage (7 = primary), 8-15 wave-cycles (s_memtime / 64) per stage, 16 idle loops,
 // 17 partial chunks published, 18 failed claims, 19 stage entries, 20 chunk allocations from the global ring, 21 steals
-enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_PARTIAL = 17, ST_CLAIMFAIL = 18, ST_ENTRIES = 19, ST_GALLOC = 20, ST_STEAL = 21, ST_SCHED_CYC = 22, ST_T_INPUT = 23, ST_T_PUSH = 24, ST_T_SERVICE = 25, ST_T_BODY = 26, ST_T_ENSURE = 27, ST_T_FLUSH = 28, ST_T_SNAP = 29, ST_T_CLAIM = 30, ST_TRIPS = 32, ST_LANETRIPS = 35, ST_DRY = 38, ST_N = 40 };
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_PARTIAL = 17, ST_CLAIMFAIL = 18, ST_ENTRIES = 19, ST_GALLOC = 20, ST_STEAL = 21, ST_SCHED_CYC = 22, ST_T_INPUT = 23, ST_T_PUSH = 24, ST_T_SERVICE = 25, ST_T_BODY = 26, ST_T_ENSURE = 27, ST_T_FLUSH = 28, ST_T_SNAP = 29, ST_T_CLAIM = 30, ST_TRIPS = 32, ST_LANETRIPS = 35, ST_DRY = 38, ST_N = 40 };      // ST_N <= 64: one LDS slot per statistic
 enum { ERR_CELL_TIMEOUT = 1, ERR_POOL_EMPTY = 2, ERR_IDLE_WATCHDOG = 3, ERR_RING_FULL = 4 };
 
 struct Args {
@@ -151,10 +151,10 @@ struct Wave {
     uint32_t w_lo, w_hi;        // work items (new paths) this wave has drawn from the device-wide counter
     uint32_t victim;            // the other team this wave looks at next when its own has nothing
     bool primary_left, aborted;
-    // statistics
-    uint32_t st_recs[NQ + 1], st_misc[8];
-    unsigned long long st_cyc[NQ + 1], st_sched, t_mark, st_t[8], st_trips[3], st_lanes[3];
-    uint32_t st_dry;
+    // statistics (STATS): accumulated in the wave's LDS block, index = ST_* (registers would cost ~60 SGPRs and change the kernel measured)
+    unsigned long long* s_st;
+    unsigned long long t_mark;
+    DE_DEV void stat(int k, unsigned long long v) { if (STATS && lane_id() == 0) s_st[k] += v; }
 
     DE_DEV uint32_t* ctl(uint32_t k) const { return A.ctl + k * DE_V5_CTL_STRIDE; }
     DE_DEV uint32_t* q_head(uint32_t ring) const { return ctl(C_QUEUE0 + 2u * ring); }
@@ -217,7 +217,7 @@ struct Wave {
         uint32_t first = 0;
         if (lane_id() == 0) first = add_agent(ctl(C_FREE_HEAD), 8u);
         first = uni(first);
-        if (STATS) st_misc[ST_GALLOC - ST_IDLE]++;
+        stat(ST_GALLOC, 1);
         const uint32_t l = (uint32_t)lane_id();
         uint32_t c = 0u;
         if (l >= n_stash && l < n_stash + 8u) {
@@ -289,7 +289,7 @@ struct Wave {
             if (oc[q] != DE_V5_NONE && of[q] > 0u && (all || t - oa[q] >= A.age_max)) {
                 publish((uint32_t)q, oc[q], of[q]);
                 oc[q] = DE_V5_NONE; of[q] = 0u;
-                if (STATS) st_misc[ST_PARTIAL - ST_IDLE]++;
+                stat(ST_PARTIAL, 1);
                 any = true;
             }
         }
@@ -301,7 +301,7 @@ struct Wave {
     DE_DEV bool next_input() {
         const unsigned long long t0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const bool r = next_input_();
-        if (STATS) st_t[0] += __builtin_amdgcn_s_memrealtime() - t0;
+        if (STATS) stat(ST_T_INPUT, __builtin_amdgcn_s_memrealtime() - t0);
         return r;
     }
     DE_DEV bool next_input_() {
@@ -332,10 +332,13 @@ struct Wave {
         if (in_chunk != DE_V5_NONE && in_lo == in_hi) { free_chunk(in_chunk); in_chunk = DE_V5_NONE; }
     }
 
-    DE_DEV void mark(int stage) {
+    // statistics: the time since the last mark goes to stage STAGE (-1: the scheduler).  A template parameter: a run-time index
+    // would put the counters — and with them the whole wave state — into scratch memory
+    template <int STAGE>
+    DE_DEV void mark() {
         if (!STATS) return;
         const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        if (stage >= 0) st_cyc[stage] += t - t_mark; else st_sched += t - t_mark;
+        stat(STAGE >= 0 ? ST_CYC + STAGE : ST_SCHED_CYC, t - t_mark);
         t_mark = t;
     }
 
@@ -347,9 +350,9 @@ struct Wave {
             if (abort_seen()) return Q_EXIT;
             unsigned long long tq = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             flush_outs(false);
-            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[5] += t - tq; tq = t; }
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); stat(ST_T_FLUSH, t - tq); tq = t; }
             ensure_stash();
-            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[4] += t - tq; tq = t; }
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); stat(ST_T_ENSURE, t - tq); tq = t; }
             // one look at this team's queues: lane q reads head and tail of ring (shard, q); lanes 62 / 63 the work counter and the
             // free-chunk count.  (A team = the waves of one shard: an XCD in LOCAL mode, else the blocks with index = shard mod n_shards.)
             int ready = 0;
@@ -359,7 +362,7 @@ struct Wave {
             else if (l == 63u) ready = (int)(ld_agent(ctl(C_FREE_TAIL)) - ld_agent(ctl(C_FREE_HEAD)));
             const uint32_t work_next = (uint32_t)__builtin_amdgcn_readlane(ready, 62);
             const int free_chunks = __builtin_amdgcn_readlane(ready, 63);
-            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[6] += t - tq; tq = t; }
+            if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); stat(ST_T_SNAP, t - tq); tq = t; }
             if (work_next >= A.n_items && w_lo >= w_hi) primary_left = false;
             // the fullest queue, and how much is queued in all
             int best_q = -1, best = 0, backlog = 0;
@@ -390,21 +393,21 @@ struct Wave {
                     const int r = __builtin_amdgcn_readlane(vr, q);
                     if (r > best) { best = r; best_q = q; }
                 }
-                if (best_q >= 0) { ring = victim * NQ + (uint32_t)best_q; if (STATS) st_misc[ST_STEAL - ST_IDLE]++; }
+                if (best_q >= 0) { ring = victim * NQ + (uint32_t)best_q; stat(ST_STEAL, 1); }
             }
             if (best_q >= 0) {
                 in_ring = ring;
                 in_n = claim(q_head(ring), q_tail(ring), 1u, A.claim_k, &in_h);
-                if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); st_t[7] += t - tq; tq = t; }
-                if (in_n) { fetch_cells(); if (STATS) st_misc[ST_ENTRIES - ST_IDLE]++; return best_q; }
-                if (STATS) st_misc[ST_CLAIMFAIL - ST_IDLE]++;
+                if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); stat(ST_T_CLAIM, t - tq); tq = t; }
+                if (in_n) { fetch_cells(); stat(ST_ENTRIES, 1); return best_q; }
+                stat(ST_CLAIMFAIL, 1);
             }
             if (may_start) return Q_PRIMARY;
             // nothing to do: whatever this wave still holds may be what the others are waiting for
             if (flush_outs(true)) continue;
             if (done_local) { if (lane_id() == 0) add_agent(ctl(C_DONE), done_local); done_local = 0u; }
             if (uni(ld_agent(ctl(C_DONE))) >= A.n_items) return Q_EXIT;
-            if (STATS) st_misc[0]++;
+            stat(ST_IDLE, 1);
             // nothing will be started any more and this wave is not one of the closers: make room for the next launch's waves
             if (!primary_left && blockIdx.x >= A.closers && idle >= 32u) return Q_EXIT;
             if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
@@ -434,7 +437,7 @@ struct Wave {
                 ensure_stash();
                 (push<TARGETS>(p, fin && target == TARGETS), ...);
                 fin = false;
-                if (STATS) st_t[1] += __builtin_amdgcn_s_memrealtime() - ts0;
+                if (STATS) stat(ST_T_PUSH, __builtin_amdgcn_s_memrealtime() - ts0);
                 if (may_refill || nb == 0) {
                     dry = false;
                     bool got = false;
@@ -444,22 +447,22 @@ struct Wave {
                         if (m_need == 0ull) break;
                         const uint32_t avail = in_hi - in_lo;
                         if (avail == 0u) {
-                            if (!next_input()) { dry = true; retry_at = trips + 24u; if (STATS) st_dry++; break; }
+                            if (!next_input()) { dry = true; retry_at = trips + 24u; stat(ST_DRY, 1); break; }
                             continue;
                         }
                         const uint32_t my = (uint32_t)__popcll(m_need & ((1ull << lane_id()) - 1ull));
                         if (!busy && !got && my < avail) { idx = in_chunk * DE_V5_CH + in_lo + my; got = true; }
                         const uint32_t take = min((uint32_t)__popcll(m_need), avail);
                         in_lo += take;
-                        if (STATS) st_recs[Q] += take;
+                        stat(ST_RECS + Q, take);
                     }
                     if (got) { load_rec(rs, idx, p); st.begin(p); busy = true; }
                 }
-                if (STATS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_t[2] += __builtin_amdgcn_s_memrealtime() - ts0; }
+                if (STATS) stat(ST_T_SERVICE, __builtin_amdgcn_s_memrealtime() - ts0);
                 if (__ballot(busy) == 0ull) { if (dry || aborted) break; else continue; }
                 if ((++services & 31u) == 0u) flush_outs(false);
             }
-            if (STATS) { st_trips[Q] += 1ull; st_lanes[Q] += (unsigned long long)__popcll(__ballot(busy)); }
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, (unsigned long long)__popcll(__ballot(busy))); }
             if (busy) {
                 if (st.step(p)) { target = st.finish(p); busy = false; fin = true; }
             }
@@ -480,13 +483,13 @@ struct Wave {
             int target = -2;
             const unsigned long long tb0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             if (active) { load_rec(rs, in_chunk * DE_V5_CH + in_lo + (uint32_t)lane_id(), p); target = body(p); }
-            if (STATS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_t[3] += __builtin_amdgcn_s_memrealtime() - tb0; }
+            if (STATS) stat(ST_T_BODY, __builtin_amdgcn_s_memrealtime() - tb0);
             in_lo += n;
-            if (STATS) st_recs[Q] += n;
+            stat(ST_RECS + Q, n);
             done_local += (uint32_t)__popcll(__ballot(target == -1));
             const unsigned long long tp0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             (push<TARGETS>(p, target == TARGETS), ...);
-            if (STATS) st_t[1] += __builtin_amdgcn_s_memrealtime() - tp0;
+            if (STATS) stat(ST_T_PUSH, __builtin_amdgcn_s_memrealtime() - tp0);
         }
         leave_input();
     }
@@ -513,7 +516,7 @@ struct Wave {
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
         }
-        if (STATS) st_recs[NQ] += min(64u, w_hi - w0);
+        stat(ST_RECS + NQ, min(64u, w_hi - w0));
         push<Q_GAS>(p, target == Q_GAS);
         push<Q_CLOUD>(p, target == Q_CLOUD);
         push<Q_EVENT>(p, target == Q_EVENT);
@@ -573,22 +576,17 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
     W.in_ring = 0u; W.in_chunk = DE_V5_NONE; W.in_lo = W.in_hi = W.in_h = W.in_n = 0u; W.in_cells = DE_V5_EMPTY; W.in_k = 0u;
     W.done_local = 0u; W.primary_left = true; W.aborted = false;
     W.w_lo = W.w_hi = 0u; W.victim = W.shard;
-#pragma unroll
-    for (int q = 0; q <= NQ; ++q) { W.st_recs[q] = 0u; W.st_cyc[q] = 0ull; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) W.st_misc[k] = 0u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) W.st_t[k] = 0ull;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { W.st_trips[k] = 0ull; W.st_lanes[k] = 0ull; }
-    W.st_dry = 0u;
-    W.st_sched = 0ull; W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    __shared__ unsigned long long s_stats[STATS ? 64 : 1];
+    if (STATS) s_stats[threadIdx.x & 63u] = 0ull;
+    __syncthreads();
+    W.s_st = s_stats;
+    W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const ColdWT<LOCAL> cold{A.cold};
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
 
     for (;;) {
         const int s = W.schedule();
-        W.mark(-1);
+        W.template mark<-1>();
         if (s == Q_EXIT) break;
         const RenderArgs& a = *v5_opaque(A.ra);
         const FrameConsts& fc = *v5_opaque(fcp);
@@ -596,46 +594,43 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
         case Q_ST: {
             StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
             W.template run_loop<Q_ST, DE_V5_SVC_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+            W.template mark<Q_ST>();
         } break;
         case Q_GAS: {
             GasStage st{a.nodes, a.dens_table};
             W.template run_loop<Q_GAS, DE_V5_SVC_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+            W.template mark<Q_GAS>();
         } break;
         case Q_CLOUD: {
             CloudStage<CLAMP> st{a.clouds};
             W.template run_loop<Q_CLOUD, DE_V5_SVC_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+            W.template mark<Q_CLOUD>();
         } break;
         case Q_EVENT:
             W.template run_flat<Q_EVENT>([&](Path& p) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
+            W.template mark<Q_EVENT>();
             break;
         case Q_SURF:
             W.template run_flat<Q_SURF>([&](Path& p) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SURF>();
             break;
         case Q_SCFIN:
             W.template run_flat<Q_SCFIN>([&](Path& p) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SCFIN>();
             break;
         case Q_SURFFIN:
             W.template run_flat<Q_SURFFIN>([&](Path& p) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SURFFIN>();
             break;
         default:
             W.run_primary(a, fc);
+            W.template mark<Q_PRIMARY>();
             break;
         }
-        W.mark(s);
     }
-    if (STATS && lane_id() == 0) {
-#pragma unroll
-        for (int q = 0; q <= NQ; ++q) {
-            if (W.st_recs[q]) add_stat(A.ctl + (C_STAT0 + ST_RECS + q) * DE_V5_CTL_STRIDE, W.st_recs[q]);
-            add_stat(A.ctl + (C_STAT0 + ST_CYC + q) * DE_V5_CTL_STRIDE, W.st_cyc[q]);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) if (W.st_misc[k]) add_stat(A.ctl + (C_STAT0 + ST_IDLE + k) * DE_V5_CTL_STRIDE, W.st_misc[k]);
-        add_stat(A.ctl + (C_STAT0 + ST_SCHED_CYC) * DE_V5_CTL_STRIDE, W.st_sched);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) add_stat(A.ctl + (C_STAT0 + ST_T_INPUT + k) * DE_V5_CTL_STRIDE, W.st_t[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { add_stat(A.ctl + (C_STAT0 + ST_TRIPS + k) * DE_V5_CTL_STRIDE, W.st_trips[k]); add_stat(A.ctl + (C_STAT0 + ST_LANETRIPS + k) * DE_V5_CTL_STRIDE, W.st_lanes[k]); }
-        add_stat(A.ctl + (C_STAT0 + ST_DRY) * DE_V5_CTL_STRIDE, W.st_dry);
+    if (STATS) {
+        __syncthreads();
+        const int k = lane_id();
+        if (k < ST_N && s_stats[k]) add_stat(A.ctl + (C_STAT0 + k) * DE_V5_CTL_STRIDE, s_stats[k]);
     }
 }
