@@ -251,7 +251,8 @@ struct de_ctx {
     int v3_wpc = 14;                 // waves per CU the v3 grids are sized for (env DE_V3_WPC; per class: DE_V3_WPC_ST / _GAS / _CLOUD / _FLAT).
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
                                      // beyond ~14 waves per CU that working set outgrows the XCD's 4 MB L2 (334 ms at 32, 252 ms at 14)
-    int v3_wpc_class[4] = {0, 0, 0, 0};   // 0 = v3_wpc; index: 0 sphere trace (and primary), 1 gas, 2 cloud, 3 the straight-line stages
+    int v3_wpc_class[4] = {0, 0, 16, 0};  // 0 = the call's wave budget; index: 0 sphere trace (and primary), 1 gas, 2 cloud, 3 the straight-line stages.  Cloud: 16 since the
+                                          // tracking steps reuse their map footprint (round 4): the stage no longer lives on L2 capacity (8 / 12 / 16 / 20 / 24 / 32 waves: 186 / 176 / 174.5 / 181 / 180 / 186 ms per step)
     // render_kernel_v5 (kernel variant 5): one persistent stage-scheduler launch per call.  Each launch slot that runs it owns a chunk
     // pool, the queue rings, the control words and the cold records of its launch (launches of different slots overlap).
     struct V5State {

@@ -73,6 +73,27 @@ def test_hip_quality2_tier_matches_the_executed_reference(lut_arrays):
         assert np.sqrt(((rgb - ref)[same] ** 2).sum() / (ref[same] ** 2).sum()) <= 1e-4
 
 
+def test_hip_cloud_heavy_4k_matches_the_executed_reference(lut_arrays):
+    """BASELINE configs[3] as the reference's text computes it (tools/ref_fixtures/make.py q2c): the quality-2 tier with the cloud-heavy
+    maps, 3840x2160, `config - sunset hurricane.txt`, one sample on a lattice of 1782 pixels over the frame."""
+    from digital_earth_amd.renderer import Renderer
+    z = np.load(os.path.join(GOLDEN, "ref_q2c.npz"))
+    W, H = (int(x) for x in z["image_res"])
+    assert (W, H) == (3840, 2160) and int(z["synth_variant"]) == 1
+    r = Renderer((W, H), (0, 1, 0), seed=int(z["rng_seed"]), texture_source="synthetic", texture_quality=2, synth_seed=int(z["synth_seed"]),
+                 cloud_heavy=True)
+    r.copy_textures()
+    cam = "sunset"
+    apply_fixture_camera(r, z, cam, lut_arrays[4])
+    rad, wl, draws, verts = per_sample(z, cam, [r.debug_samples(0)])
+    same = compare_with_fixture(z, cam, rad, wl, draws, verts, "numpy", min_same=0.995)
+    r.reset_framebuffer(); r.accumulate(1)
+    hdr = r.fetch_hdr()
+    rgb = hdr[z[cam + "_u"], z[cam + "_v"]].astype(np.float64)
+    ref = z[cam + "_rgb"].astype(np.float64)
+    assert np.sqrt(((rgb - ref)[same] ** 2).sum() / (ref[same] ** 2).sum()) <= 1e-4
+
+
 def test_hip_ray_marcher_matches_the_executed_reference(lut_arrays):
     """ray_march_kernel against the reference's ray_marcher (pathtracer.py:471-685) executed under the stand-in."""
     from digital_earth_amd.renderer import Renderer

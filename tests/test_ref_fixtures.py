@@ -175,6 +175,17 @@ def test_quality2_fixture_records_the_oracles_agreement():
         assert same >= 0.998 and med <= 1e-6 and q99 <= 3e-4 and worst <= 1e-2, (cam, same, med, q99, worst)
 
 
+def test_cloud_heavy_4k_fixture_records_the_oracles_agreement():
+    """ref_q2c.npz: the same tier with the cloud-heavy maps, 3840x2160, sunset-hurricane camera (BASELINE configs[3]); the oracle's
+    agreement was measured when the vectors were written, as for ref_q2.npz."""
+    z = np.load(os.path.join(GOLDEN, "ref_q2c.npz"))
+    assert [tuple(int(x) for x in s) for s in z["sizes"]] == [(21600, 10800)] * 2 + [(16200, 8100)] + [(21600, 10800)] * 3 + [(16200, 8100)]
+    assert tuple(int(x) for x in z["image_res"]) == (3840, 2160) and int(z["synth_variant"]) == 1
+    same, med, q99, worst = z["sunset_oracle_check"]
+    assert len(z["sunset_radiance"]) == 1782
+    assert same >= 0.995 and med <= 1e-6 and q99 <= 1e-3 and worst <= 5e-2, (same, med, q99, worst)
+
+
 def compare_marcher_with_fixture(z, cam, rad, wl, draws):
     """ray_marcher (pathtracer.py:471-685) executed from the reference's text: deterministic apart from the wavelength, the pixel
     jitter and the cone samples (9-12 draws per sample).  Relative error is meaningless for the dimmest samples — the step integral

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the 1920x1080 frame under several settings of the persistent stage scheduler (render_kernel_v5) in one process.
+"""Time the 1920x1080 frame under several settings of a kernel variant (default: the persistent stage scheduler, 5) in one process.
 
   python tools/v5_sweep.py [--spp N] [--preset NAME] [--stats] "DE_V5_WPC=16,DE_V5_SHARDS=8" "DE_V5_WPC=20" ...
 Each argument is one configuration (environment knobs read at de_create); "" = defaults.  The first context's maps are shared.
@@ -11,7 +11,7 @@ from digital_earth_amd.renderer import Renderer
 from digital_earth_amd.earth_viewer import load_config
 
 args = sys.argv[1:]
-spp, preset, stats, ref = 64, None, False, None
+spp, preset, stats, ref, variant, pipelined = 64, None, False, None, 5, 0
 cfgs = []
 while args:
     a = args.pop(0)
@@ -19,6 +19,8 @@ while args:
     elif a == "--preset": preset = args.pop(0)
     elif a == "--stats": stats = True
     elif a == "--ref": ref = int(args.pop(0))
+    elif a == "--variant": variant = int(args.pop(0))
+    elif a == "--pipelined": pipelined = int(args.pop(0))      # frames issued back to back (launch slots overlap them), one wait at the end
     else: cfgs.append(a)
 if not cfgs: cfgs = [""]
 W, H = 1920, 1080
@@ -43,7 +45,7 @@ for cfg in cfgs:
         saved[k] = os.environ.get(k); os.environ[k] = v
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic"); r.share_textures_from(owner)
     if preset: load_config(preset).apply(r)
-    r.set_kernel_variant(5)
+    r.set_kernel_variant(variant)
     try:
         r.reset_framebuffer(); r.accumulate(spp); r.synchronize()
         ts = []
@@ -51,6 +53,13 @@ for cfg in cfgs:
             r.reset_framebuffer(); r.synchronize()
             t0 = time.perf_counter(); r.accumulate(spp); r.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         line = "%-60s %s ms -> %.0f Msamples/s" % (cfg or "(defaults)", " ".join("%.1f" % t for t in ts), W * H * spp / min(ts) / 1e3)
+        if pipelined:
+            for _ in range(2):
+                r.synchronize(); t0 = time.perf_counter()
+                for _ in range(pipelined):
+                    r.reset_framebuffer(); r.accumulate(spp)
+                r.synchronize(); tp = (time.perf_counter() - t0) * 1e3 / pipelined
+            line += "  | pipelined %.1f ms/frame" % tp
         if ref_hdr is not None:
             line += "  bit-identical %.6f" % float((r.fetch_hdr().view(np.uint32) == ref_hdr.view(np.uint32)).mean())
         print(line, flush=True)
