@@ -254,10 +254,10 @@ def main():
         barrier()
         return time.perf_counter() - ta
 
-    # every launch slot of every context allocates its record buffer at its first launch; a context whose calls are a SHARE of the
-    # frame (tile partition: 8 M .. 96 M paths per call) also times its first 64 such calls on both kernels before it settles on
-    # one (include/digital_earth.h, de_set_kernel_variant): let it settle before the timed region
-    n_prime = 66 if (world > 1 or args.simulate_world > 1) else 3
+    # every launch slot of every context allocates its record buffer (and its pipe's queues) at its first launch: one frame per
+    # launch slot and pipe (four pipes for a rank's share of the frame), untimed.  Nothing is measured or decided in these frames —
+    # the launch policy no longer times kernels against each other (round 4) — so the count is a constant, reported in the line.
+    n_prime = 4
     for f in frames:
         for _ in range(n_prime):
             step(f)
@@ -303,8 +303,10 @@ def main():
         elapsed, avg_kernel_ms, single_frame_ms, alt["elapsed_s"] = (float(x) for x in t.tolist())
         # what every rank measured on its own (HIP events): render launch, collective; and the tiles it owns
         per_rank = [None] * world
+        info = r.last_call_info()
         dist.all_gather_object(per_rank, {"rank": rank, "render_ms": my_render_ms, "reduce_ms": my_reduce_ms,
-                                          "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank])})
+                                          "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank]),
+                                          "kernel": info["kernel"], "launches_per_call": info["launches"]})
         if args.check_spp > 0:
             # parity of the N-rank path on THIS hardware: the assembled frame must equal a 1-rank render bit for bit.
             # Untimed and after the measurement; a failure here is reported in the line, it does not lose the measurement.
@@ -377,13 +379,14 @@ def main():
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
                    "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
-                   "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3, "waves_per_cu": wpc,
+                   "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3, "waves_per_cu": wpc, "primed_frames": n_prime,
+                   "kernel": r.last_call_info()["kernel"],
                    "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                     "kernel": ("de_accumulate(%d): kernel variant %s — v3_* stage kernels (wavefront pipeline, first vertex rounds, batches side by side) + render_kernel_v2<false, 0> (finisher); "
-                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"))) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
+                     "kernel": ("de_accumulate(%d): kernel variant %s — %s; "
+                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), r.last_call_info()["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
                      "note": "the path is VALU-issue / divergence bound, not HBM bound (SURVEY §8d): see valu"},
         "valu": {"unit": "see fields", "loop_steps_per_sample": steps_per_sample,
@@ -437,8 +440,49 @@ def main():
                          "bit_identical_fraction_pipeline_kernels": float((g3 == c).mean()),
                          "note": "vs oracle/ (the build's CPU restatement, itself held to the reference's executed text by tests/test_ref_fixtures.py; Taichi-internal arithmetic is defined, not pinned: DESIGN §2)"}
         out["speedup_vs_cpu_port"] = value / base["value"]
+    if world > 1 and backend == "nccl" and args.reduce == "torch" and args.check_spp > 0 and not os.environ.get("DE_NO_LIB_LEG"):
+        # The library's own communicator (de_comm_init / de_reduce: RCCL bound with dlopen, ncclCommInitRank declared by hand) has
+        # never run between two GPUs on the builder's box: give it ONE untimed frame here, after everything that is measured, and
+        # report whether its assembled frame equals the torch.distributed one bit for bit.  A watchdog prints the line without it
+        # if the leg hangs: the measurement is never hostage to this check.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["lib_reduce"] = {"error": "timed out after 120 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            frame.render_frame(args.check_spp)
+            barrier()
+            ref_hdr = frame.r.fetch_hdr() if rank == 0 else None
+            lr = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)
+            if args.preset:
+                apply_preset(lr, args.preset)
+            lr.set_integrator(args.integrator)
+            lr.share_textures_from(r)
+
+            def exchange(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            lf = parallel.LibraryComm(lr, rank, world, exchange)
+            lf.render_frame(args.check_spp)
+            lr.synchronize()
+            if rank == 0:
+                lib_hdr = lf.fetch_hdr()
+                out["lib_reduce"] = {"spp": args.check_spp, "reduce_ms": lf.last_reduce_ms(),
+                                     "bit_identical_fraction": float((lib_hdr.view(np.uint32) == ref_hdr.view(np.uint32)).mean())}
+            dist.barrier()
+            lf.close()
+        except Exception as exc:          # noqa: BLE001 - reported, not swallowed
+            out["lib_reduce"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        dog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         for f in frames:

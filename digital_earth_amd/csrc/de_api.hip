@@ -223,23 +223,12 @@ struct de_ctx {
         int stat_pipes = 1;
     } v3p[4];
     float auto_ratio = -1.f;         // last known (records queued for round 2) / (paths started); < 0 = none yet
-    // Calls between auto_min_items and the two-pipe size (a rank's share of a tile partition, accumulate(16)): on light views the state
-    // machine alone is 2-10 % faster, on heavier ones the pipeline (four pipes) 25-50 % — and no cheap statistic separates the two
-    // (profiles/experiments).  So the context measures: auto_mid_calls (32) such calls on the state machine, as many on the pipeline,
-    // and for each run the time between the completion of its 9th and of its last call, per path.  Completions are chained (the HDR
-    // sums keep call order), so calls that overlap finish in bunches and a window of a few completions covers anything from half to
-    // twice its calls' work; over 23 calls the error is a few per cent, and the first quarter of a run takes the allocations and the
-    // start-up of the slots.  The faster kernel (the pipeline must win by 3 %: it costs memory) is kept for auto_mid_keep calls, then
-    // both are measured again.  Nothing is waited for: the decision is taken by the first call that finds the timestamps there.
-    // env DE_AUTO_MID: 0 = as described, 1 = always the pipeline, 2 = never; DE_AUTO_MID_CALLS, DE_AUTO_MID_KEEP
-    int auto_mid_calls = 32;
-    int auto_mid_mode = 0, auto_mid_keep = 1024;
-    bool auto_mid_pipeline = false;
-    hipEvent_t mid_a[2] = {nullptr, nullptr}, mid_b[2] = {nullptr, nullptr};   // completion of the 9th / of the last call of a measuring run
-    unsigned long long mid_items[2] = {0, 0};      // paths of the calls between them
-    bool mid_b_recorded[2] = {false, false};
-    int mid_phase = 0, mid_calls = 0;        // 0: measuring the state machine, 1: measuring the pipeline, 2: decided
-    float mid_ns[2] = {-1.f, -1.f};          // last measurement, ns per path: [0] state machine, [1] pipeline
+    // Calls between auto_min_items and the two-pipe size (a rank's share of a tile partition, accumulate(16)) run the pipeline on four
+    // pipes.  Rounds 3 picked the kernel for them by timing 32 calls on each (the state machine alone was 2-10 % faster on light views);
+    // since the cloud stage reuses its map footprints (round 4) the pipeline wins or ties on every camera and share measured
+    // (profiles/experiments: world 2 / 4 / 8 x four cameras; worst case -4 % / -9 % on the default / Apollo camera at 1/8 frame against
+    // +24 % ... +45 % elsewhere), so the measuring state machine is gone.  env DE_AUTO_MID: 1 = the pipeline (default), 2 = the state machine
+    int auto_mid_mode = 1;
     float auto_ns_per_path = -1.f;   // last known duration of a pipeline launch / its paths / the pipes running side by side
     bool auto_deep = false;          // the deep setting is in use (hysteresis: entered above auto_deep_ns, left below 0.8 x)
     int v3_pipes = 1;
@@ -278,6 +267,7 @@ struct de_ctx {
     int launch_variant = 2;          // variant of the sub-launch being issued
     int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
     int launch_slot = 0;             // launch slot of the sub-launch being issued
+    int last_call[4] = {0, 0, 0, 0}; // what the last de_accumulate ran: variant, pipes, pipeline rounds, launches (de_last_call_info)
     int launch_pipes = 1;            // pipes the call being issued runs side by side
     int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
     // variant 4 (automatic).  Measured on BASELINE's cameras (1920x1080, profiles/r3d_summary.md, profiles/experiments/): three vertex
@@ -809,8 +799,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
-        env_int("DE_AUTO_MID", &c->auto_mid_mode, 0); env_int("DE_AUTO_MID_KEEP", &c->auto_mid_keep, 1);
-        env_int("DE_AUTO_MID_CALLS", &c->auto_mid_calls, 8);
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -849,7 +838,6 @@ int de_create(int device, int width, int height, de_ctx** out) {
             if (e == hipSuccess) e = hipEventCreate(&s.t1);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) { e = hipEventCreate(&c->mid_a[i]); if (e == hipSuccess) e = hipEventCreate(&c->mid_b[i]); }
     }
     if (e == hipSuccess) e = hipMalloc(&c->d_hdr_own, npx * 3 * sizeof(float));
     c->d_hdr = c->d_hdr_own;
@@ -916,7 +904,6 @@ int de_destroy(de_ctx* c) {
         if (s.stream) hipStreamDestroy(s.stream);
     }
     if (c->ev_main) hipEventDestroy(c->ev_main);
-    for (int i = 0; i < 2; ++i) { if (c->mid_a[i]) hipEventDestroy(c->mid_a[i]); if (c->mid_b[i]) hipEventDestroy(c->mid_b[i]); }
     if (c->ev_r0) hipEventDestroy(c->ev_r0);
     if (c->ev_r1) hipEventDestroy(c->ev_r1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1098,8 +1085,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     const bool v2 = c->kernel_variant != 1 && !(c->p.flags & DE_FLAG_RAY_MARCHER);     // per-sample records + accumulate_kernel
     // does this call go through the wavefront pipeline, and with which settings
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
-    bool pipeline = false, mid_call = false;
-    int mid_idx = -1;                 // index of this call in a measuring phase of the mid-size policy
+    bool pipeline = false;
     int pipes = 1, batches = c->v3_batches;
     if (c->kernel_variant == 3 && v2 && !c->count) {
         pipeline = true; pipes = c->v3_pipes; c->launch_depths = c->v3_depths; c->launch_wpc = c->v3_wpc;
@@ -1117,33 +1103,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         }
         (void)hipGetLastError();      // hipErrorNotReady of a query is not an error of this call
         const bool two_pipe_size = call_items / 2ull > c->auto_two_pipe_items;
-        mid_call = !two_pipe_size && c->auto_pipes <= 0;
-        if (mid_call) {
-            if (c->auto_mid_mode == 1) c->auto_mid_pipeline = true;
-            else if (c->auto_mid_mode == 2) c->auto_mid_pipeline = false;
-            else {
-                if (c->mid_phase == 0 && c->mid_calls >= c->auto_mid_calls) { c->mid_phase = 1; c->mid_calls = 0; }
-                else if (c->mid_phase == 1 && c->mid_calls >= c->auto_mid_calls && c->mid_b_recorded[0] && c->mid_b_recorded[1] && hipEventQuery(c->mid_b[1]) == hipSuccess) {
-                    float t0 = 0.f, t1 = 0.f;
-                    if (hipEventElapsedTime(&t0, c->mid_a[0], c->mid_b[0]) == hipSuccess && hipEventElapsedTime(&t1, c->mid_a[1], c->mid_b[1]) == hipSuccess
-                        && c->mid_items[0] && c->mid_items[1]) {
-                        c->mid_ns[0] = t0 * 1e6f / (float)c->mid_items[0];
-                        c->mid_ns[1] = t1 * 1e6f / (float)c->mid_items[1];
-                        c->auto_mid_pipeline = c->mid_ns[1] < 0.97f * c->mid_ns[0];
-                        if (c->trace) fprintf(stderr, "[de] mid-size measurement: state machine %.2f ms for %llu paths, pipeline %.2f ms for %llu paths\n", t0, c->mid_items[0], t1, c->mid_items[1]);
-                    } else c->auto_mid_pipeline = false;
-                    c->mid_phase = 2; c->mid_calls = 0;
-                } else if (c->mid_phase == 2 && c->mid_calls >= c->auto_mid_keep) {
-                    c->mid_phase = 0; c->mid_calls = 0;
-                    c->mid_items[0] = c->mid_items[1] = 0; c->mid_b_recorded[0] = c->mid_b_recorded[1] = false;
-                }
-                (void)hipGetLastError();
-                if (c->mid_phase == 0) c->auto_mid_pipeline = false;
-                else if (c->mid_phase == 1) c->auto_mid_pipeline = true;
-                mid_idx = c->mid_calls++;
-            }
-        }
-        if (two_pipe_size || c->auto_pipes > 0 || c->auto_mid_pipeline) {
+        const bool mid_pipeline = c->auto_mid_mode != 2;      // calls below the two-pipe size
+        if (two_pipe_size || c->auto_pipes > 0 || mid_pipeline) {
             pipeline = true; c->launch_depths = c->auto_depths; c->launch_wpc = c->auto_wpc;
             pipes = c->auto_pipes > 0 ? c->auto_pipes : (two_pipe_size ? 2 : 4);
             if (c->auto_ns_per_path >= 0.f) {
@@ -1157,8 +1118,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             }
         }
         if (c->trace)
-            fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f); mid-size calls: phase %d, state machine %.2f / pipeline %.2f ns per path: %s, depths %d pipes %d batches %d\n",
-                    call_items, c->auto_ns_per_path, c->auto_ratio, c->mid_phase, c->mid_ns[0], c->mid_ns[1], pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
+            fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f): %s, depths %d pipes %d batches %d\n",
+                    call_items, c->auto_ns_per_path, c->auto_ratio, pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
     const bool v5k = c->kernel_variant == 5 && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? 2 : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
@@ -1200,6 +1161,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
     }
     bool first = true;
+    c->last_call[0] = 0; c->last_call[1] = 1; c->last_call[2] = 0; c->last_call[3] = 0;
     for (int done = 0; done < spp && a.n_tiles > 0;) {
         bool this_v3 = v3k;
         int n = (spp - done < max_spp) ? spp - done : max_spp;
@@ -1270,6 +1232,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             return hipSuccess;
         };
         HIP_TRY(c->count ? launch_render<1>(c, a, s.stream, pre_acc) : launch_render<0>(c, a, s.stream, pre_acc));
+        c->last_call[0] = (c->p.flags & DE_FLAG_RAY_MARCHER) ? 0 : c->launch_variant;
+        c->last_call[1] = this_v3 ? n_cycle : 1; c->last_call[2] = this_v3 ? c->launch_depths : 0; c->last_call[3]++;
         HIP_TRY(hipEventRecord(s.done, s.stream));
         s.pending = true;
         c->last_slot = si;
@@ -1277,16 +1241,18 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         done += n;
         if (done >= spp) {
             HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true;
-            if (mid_call && mid_idx >= 0 && c->mid_phase < 2) {
-                const int m = c->mid_phase;
-                const int L = c->auto_mid_calls;
-                if (mid_idx == L / 4) HIP_TRY(hipEventRecord(c->mid_a[m], s.stream));
-                if (mid_idx > L / 4 && mid_idx < L) c->mid_items[m] += call_items;
-                if (mid_idx == L - 1) { HIP_TRY(hipEventRecord(c->mid_b[m], s.stream)); c->mid_b_recorded[m] = true; }
-            }
         }
     }
     c->current_spp += spp;
+    return DE_OK;
+}
+
+int de_last_call_info(de_ctx* c, int* variant, int* pipes, int* depths, int* launches) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    if (variant) *variant = c->last_call[0];
+    if (pipes) *pipes = c->last_call[1];
+    if (depths) *depths = c->last_call[2];
+    if (launches) *launches = c->last_call[3];
     return DE_OK;
 }
 

@@ -382,6 +382,15 @@ class Renderer:
         loops.  Identical results, bit for bit."""
         check(self._lib.de_set_kernel_variant(self._h, int(variant)))
 
+    def last_call_info(self):
+        """What the last accumulate() ran: dict(variant, pipes, depths, launches, kernel) — include/digital_earth.h."""
+        v = [ctypes.c_int() for _ in range(4)]
+        check(self._lib.de_last_call_info(self._h, *[ctypes.byref(x) for x in v]))
+        variant, pipes, depths, launches = (int(x.value) for x in v)
+        name = {0: "ray marcher", 1: "per-lane loops", 2: "state machine", 5: "persistent stage scheduler",
+                3: "pipeline x%d, %d rounds%s" % (pipes, depths, " + state machine" if depths < 25 else "")}.get(variant, "?")
+        return dict(variant=variant, pipes=pipes, depths=depths, launches=launches, kernel=name)
+
     def v5_stats(self, n=24):
         """Statistics block of the persistent stage scheduler (kernel variant 5 with DE_V5_STATS=1); include/digital_earth.h."""
         out = (ctypes.c_uint64 * n)()

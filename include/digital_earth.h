@@ -209,14 +209,18 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *   4 (default)  automatic: a large call runs its first three vertex rounds in the wavefront pipeline (variant 3's stage kernels,
  *                batches side by side) and the surviving paths finish in the state machine (variant 2).  Large = more than 96 M
  *                paths: always (two batches; views with long paths — GPU time per path of EARLIER calls, read without waiting —
- *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the context times
- *                a run of 32 calls on either kernel and keeps the faster one for 1024 calls.  Smaller calls run variant 2 alone,
- *                overlapping through the launch slots.  The choices move time, never bits
+ *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the pipeline on four
+ *                pipes.  Smaller calls run variant 2 alone, overlapping through the launch slots.  The choices move time, never bits
  *   2            wave-level state machine only (render_kernel_v2.hip)
  *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
  *   1            per-lane loops (render_kernel.hip)
- * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..4 selects the variant at de_create. */
+ *   5            persistent stage scheduler: ONE launch whose waves pick the fullest of seven chunked HBM queues (render_kernel_v5.hip)
+ * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..5 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
+/* What the last de_accumulate call ran (any pointer may be NULL): *variant = the kernel of its launches (1, 2, 3 = the wavefront pipeline —
+ * with the state machine as finisher when *depths < 25 —, 5 = the persistent stage scheduler, 0 = the ray marcher), *pipes = pipelines side
+ * by side, *depths = vertex rounds run in the pipeline, *launches = launches the call was cut into.  For a host that reports what it measured. */
+int de_last_call_info(de_ctx* ctx, int* variant, int* pipes, int* depths, int* launches);
 
 /* Debug / test hooks.
  * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
