@@ -83,6 +83,8 @@ SYMBOLS = {
     "de_set_kernel_variant": (ctypes.c_int, [_P, ctypes.c_int]),
     "de_debug_samples": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_int, _P]),
     "de_debug_sched_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
+    "de_set_memory_budget": (ctypes.c_int, [_P, ctypes.c_uint64]),
+    "de_get_memory_use": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "de_last_call_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "de_debug_v5_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),

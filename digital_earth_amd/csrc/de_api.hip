@@ -236,6 +236,8 @@ struct de_ctx {
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
     size_t v3_max_items = (size_t)1 << 27;   // paths per batch (512 B each: 68 GB per pipe at 2^27 = a whole 1920x1080x64-spp frame; v3_reserve asks the device first and the batch shrinks when there is no room); env DE_V3_MAX_ITEMS
     size_t v3_test_budget = 0;       // env DE_V3_TEST_BUDGET (paths): see v3_reserve
+    size_t mem_budget = 0;           // de_set_memory_budget: bytes the context may hold in stage queues / cold records / chunk pools (0 = automatic:
+                                     // whatever the device has free minus 8 GB, at most 2^27 paths per batch)
     int v3_slack_wpc = 14;           // the largest wave budget any stage grid may get (set after the env knobs are read): sizes the queues' room for holes
     int v3_wpc = 14;                 // waves per CU the v3 grids are sized for (env DE_V3_WPC; per class: DE_V3_WPC_ST / _GAS / _CLOUD / _FLAT).
                                      // NOT the 32 the CU can hold: 64 paths per wave each keep a map line hot between two steps, and
@@ -447,6 +449,11 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     // 512 B per path: ask first — other contexts, the host framework and the next pipe want memory too (8 GB stay free)
     size_t free_b = 0, total_b = 0;
     const size_t need_b = (size_t)wf::NQ * (n_items + slack) * sizeof(wf::Rec) + n_items * sizeof(wf::Cold);
+    if (c->mem_budget) {
+        // the call's pipes run side by side and are sized alike: each gets its share of the budget
+        const size_t share = c->mem_budget / (size_t)(c->launch_pipes > 0 ? c->launch_pipes : 1);
+        if (need_b > share) return V3_NO_MEMORY;
+    }
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need_b + ((size_t)8 << 30)) return V3_NO_MEMORY;
     if (c->v3_test_budget && n_items > c->v3_test_budget) return V3_NO_MEMORY;      // tests: pretend larger queues do not fit
     bool ok = true;
@@ -1121,6 +1128,26 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f): %s, depths %d pipes %d batches %d\n",
                     call_items, c->auto_ns_per_path, c->auto_ratio, pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
+    if (pipeline && c->mem_budget && a.n_tiles > 0) {
+        // A budget that is binding — a pipe's share holds less than the batch the call would use — cuts the call into more, smaller
+        // launches, each with its own tails.  Measured (profiles/memory_budget.md): batches under ~24 M paths lose to the state
+        // machine in one launch on light views.  So: fewer pipes first (two), and below that size no pipeline for this call.
+        const size_t slack_b = (size_t)wf::NQ * (4u * (size_t)c->n_cus * (size_t)c->v3_slack_wpc * DE_V3_BULK) * sizeof(wf::Rec);
+        auto fit_of = [&](int np) { const size_t share = c->mem_budget / (size_t)np; return share > slack_b ? (share - slack_b) / 512u : (size_t)0; };
+        const int nb = batches > pipes ? batches : pipes;
+        size_t nominal = (size_t)(call_items / (unsigned long long)(nb > 0 ? nb : 1));
+        if (nominal > c->v3_max_items) nominal = c->v3_max_items;
+        const size_t floor_items = (size_t)24 << 20;
+        if (fit_of(pipes) < nominal && c->launch_depths != c->auto_depths) {
+            // the deep setting (more rounds, a third pipe) is chosen from the GPU time per path of earlier launches, which small batches inflate
+            c->launch_depths = c->auto_depths;
+            if (c->auto_pipes <= 0 && pipes > 2) { pipes = 2; batches = c->v3_batches; }
+        }
+        if (fit_of(pipes) < nominal && fit_of(pipes) < floor_items) {
+            if (pipes > 2 && fit_of(2) >= floor_items) { pipes = 2; if (batches > 2) batches = 2; }
+            else pipeline = false;
+        }
+    }
     const bool v5k = c->kernel_variant == 5 && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? 2 : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
@@ -1144,7 +1171,15 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (pipes >= 2 && nb >= 2 && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if (v5k) {   // 64 B of cold record per path of a launch
-            unsigned long long cap5 = (unsigned long long)c->v5_max_items / (nt * 64ull);
+            unsigned long long max5 = (unsigned long long)c->v5_max_items;
+            if (c->mem_budget) {      // three launch slots in flight, each: the chunk pool + rings, and 64 B of cold record per path
+                const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
+                const unsigned long long share = (unsigned long long)c->mem_budget / 3ull;
+                const unsigned long long fit = share > fixed ? (share - fixed) / 64ull : 0ull;
+                if (fit < max5) max5 = fit;
+                if (max5 < nt * 64ull) return fail(DE_ERR_NOMEM, "the memory budget has no room for one sample per pixel on the persistent stage scheduler (de_set_memory_budget)");
+            }
+            unsigned long long cap5 = max5 / (nt * 64ull);
             if (cap5 < 1) cap5 = 1;
             if (cap > cap5) cap = cap5;
             const int nb = c->v5_batches < spp ? c->v5_batches : spp;
@@ -1244,6 +1279,44 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         }
     }
     c->current_spp += spp;
+    return DE_OK;
+}
+
+namespace {
+void free_queue_memory(de_ctx* c) {
+    for (auto& P : c->v3p) {
+        for (int i = 0; i < wf::NQ; ++i) { if (P.rec[i]) hipFree(P.rec[i]); P.rec[i] = nullptr; }
+        if (P.cold) hipFree(P.cold);
+        P.cold = nullptr; P.capacity = 0;
+    }
+    for (auto& S : c->v5s) {
+        if (S.pool) hipFree(S.pool); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring); if (S.cold) hipFree(S.cold);
+        S.pool = nullptr; S.rings = nullptr; S.free_ring = nullptr; S.cold = nullptr; S.cold_items = 0; S.pool_chunks = 0;
+    }
+}
+}  // namespace
+
+int de_set_memory_budget(de_ctx* c, uint64_t bytes) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    free_queue_memory(c);                 // what is held may exceed the new budget: the next large call allocates within it
+    c->mem_budget = (size_t)bytes;
+    return DE_OK;
+}
+int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
+    if (!c || !queue_bytes) return fail(DE_ERR_INVALID, "null argument");
+    uint64_t n = 0;
+    for (auto& P : c->v3p) {
+        if (!P.capacity) continue;
+        const size_t slack = 4u * (size_t)c->n_cus * (size_t)c->v3_slack_wpc * DE_V3_BULK;
+        n += (uint64_t)wf::NQ * (P.capacity + slack) * sizeof(wf::Rec) + (uint64_t)P.capacity * sizeof(wf::Cold);
+    }
+    for (auto& S : c->v5s) {
+        if (S.pool) n += (uint64_t)S.pool_chunks * DE_V5_CH * 64u + (uint64_t)S.n_shards * wf::NQ * S.ring_cells * 4u + (uint64_t)S.pool_chunks * 4u;
+        n += (uint64_t)S.cold_items * 64u;
+    }
+    *queue_bytes = n;
     return DE_OK;
 }
 

@@ -382,6 +382,15 @@ class Renderer:
         loops.  Identical results, bit for bit."""
         check(self._lib.de_set_kernel_variant(self._h, int(variant)))
 
+    def set_memory_budget(self, n_bytes):
+        """Bytes the context may hold in pipeline queues / cold records / chunk pools (0 = automatic); include/digital_earth.h."""
+        check(self._lib.de_set_memory_budget(self._h, ctypes.c_uint64(int(n_bytes))))
+
+    def memory_use(self):
+        n = ctypes.c_uint64()
+        check(self._lib.de_get_memory_use(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def last_call_info(self):
         """What the last accumulate() ran: dict(variant, pipes, depths, launches, kernel) — include/digital_earth.h."""
         v = [ctypes.c_int() for _ in range(4)]

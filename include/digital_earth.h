@@ -217,6 +217,13 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *   5            persistent stage scheduler: ONE launch whose waves pick the fullest of seven chunked HBM queues (render_kernel_v5.hip)
  * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..5 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
+/* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
+ * persistent scheduler's pools: a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
+ * pixel that does not fit runs on the state machine).  0 (default) = automatic: what the device has free minus 8 GB, at most 2^27 paths
+ * per batch.  Setting it releases what is held.  profiles/memory_budget.md: throughput against the budget.
+ * de_get_memory_use: bytes currently held for these buffers. */
+int de_set_memory_budget(de_ctx* ctx, uint64_t bytes);
+int de_get_memory_use(de_ctx* ctx, uint64_t* queue_bytes);
 /* What the last de_accumulate call ran (any pointer may be NULL): *variant = the kernel of its launches (1, 2, 3 = the wavefront pipeline —
  * with the state machine as finisher when *depths < 25 —, 5 = the persistent stage scheduler, 0 = the ray marcher), *pipes = pipelines side
  * by side, *depths = vertex rounds run in the pipeline, *launches = launches the call was cut into.  For a host that reports what it measured. */

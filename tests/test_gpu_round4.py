@@ -49,8 +49,8 @@ def test_cfg4_quality2_cloud_heavy_full_sample_count(Renderer, lut_arrays):
 @pytest.mark.timeout(3000)
 def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arrays):
     """BASELINE configs[4]: 1920x1080, 1024 spp PROGRESSIVE (a display after every 128 samples), `config - Apollo 11.txt`, quality-2
-    maps, the camera-response curve selected BY NAME — the preset's index 12 counts os.listdir order on the author's machine (Q10);
-    under this repo's pinned order (Neutral first, then sorted) it is dscs315-5.rf, the name the executed-reference fixtures carry.
+    maps, the camera-response curve selected BY NAME — the preset's index 12 counts os.listdir order on the author's machine (Q10):
+    the curve is taken by the name the executed-reference fixtures carry for this preset, not by the index.
     Oracle: every 97th tile at all 1024 spp, HDR bit for bit, and the displayed pixels through the same film curve."""
     import os
     from digital_earth_amd import parallel
@@ -60,14 +60,16 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_quality=2, seed=13)
     r.copy_textures()
     p = _apply(r, "config - Apollo 11.txt", crf_by_name=name)
-    assert r.crf_names[p["crf"]] == name and name != "Neutral.rf"
+    # (the preset's index 12 is another curve under this repo's pinned order: which one the author saw is not knowable, DESIGN §2 Q10;
+    # the fixtures carry the name the executed reference resolved it to in the build container)
+    assert name in r.crf_names and name != "Neutral.rf" and r._params.selected_crf == r.crf_names.index(name)
     shown = []
     while r.current_spp < SPP:
         r.accumulate(EVERY)
         shown.append(float(r.fetch_image().mean()))          # the progressive display (renderer.py:382-384)
     g, img = r.fetch_hdr(), r.fetch_image()
     assert len(shown) == SPP // EVERY and np.isfinite(g).all() and g.max() > 0
-    assert max(shown) - min(shown) < 0.02 * max(shown)        # the displayed frame converges instead of brightening with the sample count
+    assert abs(shown[-1] - shown[-2]) < 0.005 * shown[-1] and max(shown) < 1.05 * min(shown)   # the display converges; it does not brighten with the sample count
     o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
     o.accumulate(SPP, 13, 41, 97)
     mask = parallel.owned_pixel_mask(W, H, 41, 97)
@@ -75,3 +77,35 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
     assert (o.fetch_hdr()[mask].view(np.uint32) == g[mask].view(np.uint32)).all()
     assert np.abs(o.fetch_image()[mask] - img[mask]).max() <= 1e-5
     assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01
+
+
+def test_memory_budget_cuts_the_batches_not_the_bits(Renderer):
+    """de_set_memory_budget: 1920x1088 x 64 spp = 134 M paths in two batches on two pipes, 512 B per path and pipe plus
+    each pipe's room for holes (1.9 GB): 72 GB.  With 60 GB the pipes get 30 GB each: the batches shrink (more launches), the memory
+    held stays inside the budget, the frame is the state machine's bit for bit; with a budget that leaves a pipe room for less than a
+    worthwhile batch the call runs on the state machine, in one launch."""
+    from helpers import bits_equal_fraction
+    W, H, SPP = 1920, 1088, 64
+    kw = dict(seed=17, texture_source="synthetic", texture_size=(4096, 2048))
+    ref = Renderer((W, H), (0, 1, 0), **kw); ref.set_kernel_variant(2); ref.accumulate(SPP)
+    want = ref.fetch_hdr()
+    r = Renderer((W, H), (0, 1, 0), **kw)
+    r.accumulate(SPP); r.synchronize()
+    free_launches, free_bytes = r.last_call_info()["launches"], r.memory_use()
+    assert r.last_call_info()["variant"] == 3 and free_bytes > 0
+    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
+    budget = 60 << 30
+    r.set_memory_budget(budget)
+    assert r.memory_use() == 0                                   # setting it releases what was held
+    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
+    info = r.last_call_info()
+    assert info["variant"] == 3 and info["launches"] > free_launches, (info, free_launches)
+    assert 0 < r.memory_use() <= budget
+    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
+    r.set_memory_budget(8 << 30)                                 # 4 GB per pipe: 4 M paths, not worth a pipeline launch
+    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
+    assert r.last_call_info()["variant"] == 2 and r.last_call_info()["launches"] == 1 and r.memory_use() == 0
+    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
+    r.set_memory_budget(0)
+    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
+    assert r.last_call_info()["launches"] == free_launches
