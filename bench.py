@@ -359,7 +359,9 @@ def main():
                 prof_ms = pj.get("kernel_ms")
                 if prof_ms and abs(avg_kernel_ms - prof_ms) <= 0.03 * prof_ms:
                     traffic = pj.get("hbm_bytes_per_launch")
-                    traffic_note = pj.get("note", "")
+                    traffic_note = ("REPLAYED, not measured in this run: `traffic` and the `valu.issue` block come from the committed rocprofv3 --pmc "
+                                    "passes of this workload (profiles/hbm_traffic.json, profile %s), admitted because this run's launch duration is "
+                                    "within 3 %% of the profiled one.  " % pj.get("profile")) + pj.get("note", "")
                     valu_insts, lane_util = pj.get("valu_insts_per_launch"), pj.get("valu_lane_utilisation")
                     prof_name = pj.get("profile")
                 else:

@@ -768,28 +768,16 @@ int load_rccl() {
 
 }  // namespace
 
-extern "C" {
-
-const char* de_last_error(void) { return g_err.c_str(); }
-int de_abi_version(void) { return DE_ABI_VERSION; }
-int de_arithmetic_contract(void) { return DE_ARITHMETIC_CONTRACT; }
-
-int de_create(int device, int width, int height, de_ctx** out) {
-    if (!out) return fail(DE_ERR_INVALID, "out is null");
-    if (width <= 0 || height <= 0 || width % 16 || height % 8)
-        return fail(DE_ERR_INVALID, "image size must be a positive multiple of (16, 8) (renderer.py:46)");
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(DE_ERR_NO_DEVICE, "no HIP device: libdigitalearth_hip has no CPU path");
-    if (device < 0 || device >= n_dev) return fail(DE_ERR_INVALID, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(DE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
-    de_ctx* c = new de_ctx();
-    c->device = device; c->W = width; c->H = height;
-    default_params(&c->p);
+namespace {
+// Every environment override of the library, read ONCE per context here (experiments, tests, A/B sweeps; none is needed in production
+// and none is read again later):
+//   DE_KERNEL             kernel variant 1..5 (de_set_kernel_variant)             DE_AUTO_TRACE   print what the launch policy chose
+//   DE_V2_THR / _A / _B / _G / _CHUNK / _WPC / _MAX_SPP     render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split
+//   DE_V3_MAX_ITEMS / _WPC / _WPC_{ST,GAS,CLOUD,FLAT} / _PIPES / _BATCHES / _DEPTHS / _TEST_BUDGET      the pipeline alone (variant 3)
+//   DE_AUTO_DEPTHS / _WPC / _PIPES / _MIN_ITEMS / _TWO_PIPE_ITEMS / _MID / _DEEP_NS / _DEEP_DEPTHS / _DEEP_PIPES     the default's policy
+//   DE_V5_WPC / _SHARDS / _LOCAL / _POOL_LOG2 / _CLAIM_K / _AGE / _CLOSERS / _STATS / _BACKLOG / _RESERVE_PCT / _BATCHES / _MAX_ITEMS   variant 5
+//   DE_SLOTS / DE_BIG_SLOTS   launch slots (read next to their creation in de_create)
+void read_env_knobs(de_ctx* c) {
     c->trace = getenv("DE_AUTO_TRACE") != nullptr;
     if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '5') c->kernel_variant = kv[0] - '0'; }
     c->launch_variant = (c->kernel_variant == 4 || c->kernel_variant == 5) ? 2 : c->kernel_variant;
@@ -826,6 +814,33 @@ int de_create(int device, int width, int height, de_ctx** out) {
         if (c->v3_slack_wpc > 32) c->v3_slack_wpc = 32;
         if (c->v3_slack_wpc < 1) c->v3_slack_wpc = 1;
     }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* de_last_error(void) { return g_err.c_str(); }
+int de_abi_version(void) { return DE_ABI_VERSION; }
+int de_arithmetic_contract(void) { return DE_ARITHMETIC_CONTRACT; }
+
+int de_create(int device, int width, int height, de_ctx** out) {
+    if (!out) return fail(DE_ERR_INVALID, "out is null");
+    if (width <= 0 || height <= 0 || width % 16 || height % 8)
+        return fail(DE_ERR_INVALID, "image size must be a positive multiple of (16, 8) (renderer.py:46)");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(DE_ERR_NO_DEVICE, "no HIP device: libdigitalearth_hip has no CPU path");
+    if (device < 0 || device >= n_dev) return fail(DE_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DE_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    de_ctx* c = new de_ctx();
+    c->device = device; c->W = width; c->H = height;
+    default_params(&c->p);
+    read_env_knobs(c);
     memset(&c->counters, 0, sizeof(c->counters));
     size_t npx = (size_t)width * height;
     // the context stream carries the small operations between frames and the collective: highest priority, so that wave slots

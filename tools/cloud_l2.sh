@@ -2,7 +2,7 @@
 cd /tmp; export TMPDIR=/tmp
 for w in 8 12 16 24 32; do
   rm -rf /tmp/cl2; export DE_V3_WPC_CLOUD=$w
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "v3_cloud" --output-format csv -d /tmp/cl2 -o p -- python3 $GRAFT_REPO_ROOT/tools/hybrid_try.py > /dev/null 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "v3_cloud" --output-format csv -d /tmp/cl2 -o p -- python3 $GRAFT_REPO_ROOT/tools/frame.py > /dev/null 2>&1
   python3 - $w <<'PY'
 import csv,glob,collections,sys
 rows=[]

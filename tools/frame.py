@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Two 1920x1080 frames with the persistent stage scheduler (kernel variant from DE_KERNEL, default 5): the workload of tools/v5_pmc.sh."""
+"""Two 1920x1080 frames under the kernel variant of DE_KERNEL (default 5, the persistent stage scheduler): the workload of tools/v5_pmc.sh, v3_pmc.sh, v3_run.sh, cloud_l2.sh.  usage: frame.py [spp] [preset]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from digital_earth_amd.renderer import Renderer

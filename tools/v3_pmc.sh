@@ -1,5 +1,6 @@
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/v3pmc
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "v3_" --output-format csv -d /tmp/v3pmc/a -o p -- python3 $GRAFT_REPO_ROOT/tools/v3_frame.py ${1:-16} 3 > /dev/null 2>&1
+# (the frame driver runs the kernel variant of DE_KERNEL: export DE_KERNEL=3 for the pipeline alone)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "v3_" --output-format csv -d /tmp/v3pmc/a -o p -- python3 $GRAFT_REPO_ROOT/tools/frame.py ${1:-16} > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,collections
 rows=[]

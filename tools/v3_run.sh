@@ -1,6 +1,7 @@
-# usage: v3_run.sh <spp> : per-kernel totals of the second frame of tools/v3_frame.py under rocprofv3 --kernel-trace (env DE_V3_* passes through)
+# usage: v3_run.sh <spp> : per-kernel totals of the second frame of tools/frame.py under rocprofv3 --kernel-trace (env DE_V3_* passes through)
+# (the frame driver runs the kernel variant of DE_KERNEL: export DE_KERNEL=3 for the pipeline alone)
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/v3prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/v3prof -o s -- python3 $GRAFT_REPO_ROOT/tools/v3_frame.py ${1:-64} 3 2>&1 | grep "^ms"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/v3prof -o s -- python3 $GRAFT_REPO_ROOT/tools/frame.py ${1:-64} 2>&1 | grep "^ms"
 python3 - <<PY
 import csv,glob,collections
 for f in glob.glob("/tmp/v3prof/**/*kernel_trace.csv", recursive=True):
