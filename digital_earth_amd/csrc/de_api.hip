@@ -232,6 +232,7 @@ struct de_ctx {
     float auto_ns_per_path = -1.f;   // last known duration of a pipeline launch / its paths / the pipes running side by side
     bool auto_deep = false;          // the deep setting is in use (hysteresis: entered above auto_deep_ns, left below 0.8 x)
     int v3_pipes = 1;
+    int v3_fuse_track = 0;           // 1: one kernel tracks a ray through the gases and on through the cloud shell (v3_track_kernel: bit-identical, measured 8 % slower: profiles/experiments); 0: two stage kernels (env DE_V3_FUSE_TRACK)
     int v3_depths = 25;              // vertex rounds run by the pipeline before render_kernel_v2 finishes the surviving paths (env DE_V3_DEPTHS; 25 = all)
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
     size_t v3_max_items = (size_t)1 << 27;   // paths per batch (512 B each: 68 GB per pipe at 2^27 = a whole 1920x1080x64-spp frame; v3_reserve asks the device first and the batch shrinks when there is no room); env DE_V3_MAX_ITEMS
@@ -527,13 +528,19 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
         if (depth == 2) note_round2();
         if (depth == 0) { size_grid(0); bind(); if (clamp) hipLaunchKernelGGL((v3_primary_kernel<true>), grid, block, 0, stream, A, a.fc); else hipLaunchKernelGGL((v3_primary_kernel<false>), grid, block, 0, stream, A, a.fc); }
         else V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)               // path rays of this vertex
+        if (c->v3_fuse_track) { V3_DRAIN_T(wf::Q_CLOUD, v3_track_kernel, A) P.epoch[wf::Q_GAS]++; }   // delta tracking: gases, then the cloud shell, in one lane
+        else {
         V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // delta tracking, gases
         V3_DRAIN_T(wf::Q_CLOUD, v3_cloud_kernel, A)                    // delta tracking, cloud shell
+        }
         V3_DRAIN_T(wf::Q_EVENT, v3_event_kernel, A, a.fc)              // event, light sample, branch
         V3_DRAIN_T(wf::Q_SURF, v3_surf_kernel, A, a.fc)                // surface hits: normal, material, shadow ray
         V3_DRAIN_T(wf::Q_ST, v3_st_kernel, A, a.fc)                    // shadow rays
+        if (c->v3_fuse_track) { V3_DRAIN_T(wf::Q_CLOUD, v3_track_kernel, A) P.epoch[wf::Q_GAS]++; }   // ratio tracking towards the sun
+        else {
         V3_DRAIN(wf::Q_GAS, v3_gas_kernel, A)                          // ratio tracking towards the sun, gases
         V3_DRAIN_T(wf::Q_CLOUD, v3_cloud_kernel, A)                    // ... cloud shell
+        }
         V3_DRAIN(wf::Q_SCFIN, v3_scfin_kernel, A, a.fc)                // volume vertices: shade, next direction
         V3_DRAIN(wf::Q_SURFFIN, v3_surffin_kernel, A, a.fc)            // surface vertices
     }
@@ -787,7 +794,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_V2_G", &c->tune_gas, 0); env_int("DE_V2_CHUNK", &c->tune_chunk, 1); env_int("DE_V2_WPC", &c->tune_wpc, 1);
         env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
         if (const char* e3 = getenv("DE_V3_MAX_ITEMS")) { long long x = atoll(e3); if (x >= 4096) c->v3_max_items = (size_t)x; }
-        env_int("DE_V3_WPC", &c->v3_wpc, 1);
+        env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_V3_FUSE_TRACK", &c->v3_fuse_track, 0);
         env_int("DE_V3_PIPES", &c->v3_pipes, 1); if (c->v3_pipes > 4) c->v3_pipes = 4;
         env_int("DE_V3_BATCHES", &c->v3_batches, 1);
         env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;

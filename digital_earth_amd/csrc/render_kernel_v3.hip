@@ -699,11 +699,20 @@ struct GasStage {
         const float len = length_nr(C);
         const float h2 = de_max(len - DE_PLANET_R, 0.0f) * 2.0f;
         vec3 dens;
+#ifndef DE_GAS_TABLE
+        // The profiles evaluated — what the altitude table holds, entry by entry (aux_kernels.hip: dens_table_kernel; h2 / 2 is the
+        // entry's altitude exactly), so the bits are the table's.  The state machine reads the table because it is issue-bound; a
+        // single-class gas wave is latency-bound on that read (one dependent load per 60 instructions) and four exponentials cost it
+        // less than the wait: the persistent scheduler 220 -> 194 ms per frame, the pipeline's gas kernel -1 ms (round 4).
+        (void)h2;
+        dens = get_density(de_max(len - DE_PLANET_R, 0.0f));
+#else
         if (h2 < (float)DE_DENS_TABLE_N) {
             dens = dens_table_read(dens_table, (uint32_t)(int)h2);
         } else {
             dens = get_density(len - DE_PLANET_R);
         }
+#endif
         const vec3 es = v3(ext_r, ext_m, ext_o) * dens;
         const float sum = (es.x + es.y) + es.z;
         if (kind == 0) {
@@ -807,6 +816,52 @@ struct CloudStage {
         return (kind == 1) ? wf::Q_SCFIN : wf::Q_SURFFIN;
     }
 };
+// ------------------------------------------------------------------------------------------------ TRACK: gases, then the cloud shell, in one lane
+// A ray's tracking through the gases is followed by its tracking through the cloud shell (pathtracer.py:186 -> :198, :227 -> :231) for 85 %
+// of the gas segments.  Here the lane that finishes the gas segment goes on with the cloud segment: GasStage::finish's glue runs in place,
+// the record never travels through the cloud queue (a 128-byte hop), and a wave holds lanes of both classes — an altitude-table load and a
+// map tap in flight per trip, which is what the gas stage alone lacked (one dependent load per 60 instructions: 22 % of the issue ceiling).
+// Same statements on the same generator in the same order: the bits do not move.
+template <bool CLAMP>
+struct TrackStage {
+    GasStage g;
+    CloudStage<CLAMP> c;
+    bool in_cloud;
+    int target;
+    DE_DEV void begin(wf::Path& p) { in_cloud = false; g.begin(p); }
+    DE_DEV bool step(wf::Path& p) {
+        if (!in_cloud) {
+            if (g.step(p)) {
+                target = g.finish(p);
+                if (target != wf::Q_CLOUD) return true;
+                c.begin(p);
+                in_cloud = true;
+            }
+            return false;
+        }
+        if (c.step(p)) { target = c.finish(p); return true; }
+        return false;
+    }
+    DE_DEV int finish(wf::Path&) { return target; }
+};
+#ifndef DE_V3_SVC_TRACK
+#define DE_V3_SVC_TRACK 16
+#endif
+// drains the gas queue with TrackStage, then what the sphere trace and the event stage queued for the cloud shell directly
+template <bool CLAMP>
+__global__ void __launch_bounds__(DE_V3_BLOCK) v3_track_kernel(wf::Args A) {
+    using namespace wf;
+    const int targets[3] = {Q_EVENT, Q_SCFIN, Q_SURFFIN};
+    {
+        TrackStage<CLAMP> st{GasStage{A.a.nodes, A.a.dens_table}, CloudStage<CLAMP>{A.a.clouds}, false, -1};
+        run_stage<DE_V3_SVC_TRACK>(A, A.q[Q_GAS], st, targets);
+    }
+    {
+        CloudStage<CLAMP> st{A.a.clouds};
+        run_stage<DE_V3_SVC_CLOUD>(A, A.q[Q_CLOUD], st, targets);
+    }
+}
+
 template <bool CLAMP>
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_cloud_kernel(wf::Args A) {
     using namespace wf;
