@@ -232,6 +232,8 @@ struct de_ctx {
     float auto_ns_per_path = -1.f;   // last known duration of a pipeline launch / its paths / the pipes running side by side
     bool auto_deep = false;          // the deep setting is in use (hysteresis: entered above auto_deep_ns, left below 0.8 x)
     int v3_pipes = 1;
+    int v3_finisher = 2;             // what finishes the paths the pipeline hands over: 2 = render_kernel_v2 (resume mode), 5 = render_kernel_v5 (env DE_V3_FINISHER)
+    int v5_fin_wpc = 8;              // waves per CU of a finisher launch of render_kernel_v5 (two pipes side by side; env DE_V5_FIN_WPC)
     int v3_fuse_track = 0;           // 1: one kernel tracks a ray through the gases and on through the cloud shell (v3_track_kernel: bit-identical, measured 8 % slower: profiles/experiments); 0: two stage kernels (env DE_V3_FUSE_TRACK)
     int v3_depths = 25;              // vertex rounds run by the pipeline before render_kernel_v2 finishes the surviving paths (env DE_V3_DEPTHS; 25 = all)
     int v3_batches = 2;              // with two pipes: batches a call is cut into (they alternate between the pipes; env DE_V3_BATCHES)
@@ -257,7 +259,7 @@ struct de_ctx {
         uint32_t* h_status = nullptr;     // pinned, device-visible: the kernel's abort code
         size_t cold_items = 0;
         uint32_t pool_chunks = 0, ring_cells = 0, n_shards = 0;
-    } v5s[DE_MAX_SLOTS];
+    } v5s[DE_MAX_SLOTS + 4];         // one per launch slot (kernel variant 5), then one per pipe (the pipeline's finisher, v3_finisher = 5)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
     int v5_local = 0;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
@@ -485,6 +487,9 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     P.capacity = n_items;
     return DE_OK;
 }
+int v5_reserve(de_ctx* c, int idx, hipStream_t stream, size_t n_items);
+hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx, const uint4* resume_rec = nullptr, const uint32_t* resume_count = nullptr,
+                     const float* resume_cold = nullptr, uint32_t resume_capacity = 0, int wpc = 0);
 hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pipe) {
     de_ctx::V3Pipe& P = c->v3p[pipe];
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
@@ -562,6 +567,11 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
         if (me != hipSuccess) return me;
         dim3 pgrid((unsigned)c->n_cus * (unsigned)c->tune_wpc), pblock(DE_V2_BLOCK);
         if (timed && P.stat_pending) hipEventRecord(P.ev_t[1], stream);
+        if (c->v3_finisher == 5) {
+            // the persistent stage scheduler finishes the queued path rays (round 4): the same records, resumed into its own queues
+            me = launch_v5(c, a, stream, DE_MAX_SLOTS + pipe, b.resume_rec, b.resume_count, b.resume_cold, b.resume_capacity, c->v5_fin_wpc);
+            if (me != hipSuccess) return me;
+        } else
         if (clamp) hipLaunchKernelGGL((render_kernel_v2<true, 0>), pgrid, pblock, 0, stream, b, b.fc);
         else hipLaunchKernelGGL((render_kernel_v2<false, 0>), pgrid, pblock, 0, stream, b, b.fc);
         if (timed && P.stat_pending) { hipEventRecord(P.ev_t[2], stream); hipEventRecord(P.stat_ev, stream); P.stat_timed = true; P.stat_pipes = c->launch_pipes; }
@@ -572,11 +582,11 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
 
 // render_kernel_v5: buffers of one launch slot.  Pool, rings and control words are sized once; the cold records grow with the
 // largest launch the slot has seen.
-int v5_reserve(de_ctx* c, int si, size_t n_items) {
-    de_ctx::V5State& S = c->v5s[si];
+int v5_reserve(de_ctx* c, int idx, hipStream_t stream, size_t n_items) {
+    de_ctx::V5State& S = c->v5s[idx];
     const uint32_t pool_chunks = 1u << c->v5_pool_log2;
     if (!S.pool || S.pool_chunks != pool_chunks || S.n_shards != (uint32_t)c->v5_shards) {
-        HIP_TRY(hipStreamSynchronize(c->slot[si].stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
         S.pool = nullptr; S.ctl = nullptr; S.rings = nullptr; S.free_ring = nullptr;
         S.pool_chunks = pool_chunks; S.n_shards = (uint32_t)c->v5_shards;
@@ -592,7 +602,7 @@ int v5_reserve(de_ctx* c, int si, size_t n_items) {
         }
     }
     if (n_items > S.cold_items) {
-        HIP_TRY(hipStreamSynchronize(c->slot[si].stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         if (S.cold) hipFree(S.cold);
         S.cold = nullptr; S.cold_items = 0;
         if (hipMalloc(&S.cold, n_items * 64u) != hipSuccess) { (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no room for the cold records of a render_kernel_v5 launch (64 B per path): lower DE_V5_MAX_ITEMS"); }
@@ -600,8 +610,9 @@ int v5_reserve(de_ctx* c, int si, size_t n_items) {
     }
     return DE_OK;
 }
-hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si) {
-    de_ctx::V5State& S = c->v5s[si];
+hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx, const uint4* resume_rec, const uint32_t* resume_count, const float* resume_cold,
+                     uint32_t resume_capacity, int wpc) {
+    de_ctx::V5State& S = c->v5s[idx];
     const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
     ps::Args A;
     A.ra = S.d_args;
@@ -611,9 +622,11 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si)
     if (e != hipSuccess) return e;
     A.status = d_status;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
+    A.resume_rec = resume_rec; A.resume_count = resume_count; A.resume_cold = resume_cold; A.resume_capacity = resume_capacity;
+    if (wpc <= 0) wpc = c->v5_wpc;
     A.pool_chunks = S.pool_chunks; A.ring_mask = S.ring_cells - 1u; A.n_shards = S.n_shards;
     A.reserve_chunks = (uint32_t)((unsigned long long)S.pool_chunks * (unsigned)c->v5_reserve_pct / 100ull);
-    A.backlog_target = (uint32_t)((unsigned long long)c->n_cus * (unsigned)c->v5_wpc * (unsigned)c->v5_backlog / S.n_shards);
+    A.backlog_target = (uint32_t)((unsigned long long)c->n_cus * (unsigned)wpc * (unsigned)c->v5_backlog / S.n_shards);
     A.claim_k = (uint32_t)c->v5_claim_k; A.age_max = (uint32_t)c->v5_age;
     A.closers = (uint32_t)(c->n_cus * c->v5_closers_per_cu);
     A.idle_limit = 1u << 20;
@@ -623,7 +636,7 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(v5_init_kernel, dim3((S.pool_chunks + 255u) / 256u), dim3(256), 0, stream, S.ctl, S.free_ring, S.pool_chunks, a, S.d_args);
     const unsigned by_work = (unsigned)((A.n_items + 63u) / 64u);
-    const unsigned machine = (unsigned)c->n_cus * (unsigned)c->v5_wpc;
+    const unsigned machine = (unsigned)c->n_cus * (unsigned)wpc;
     dim3 grid(by_work < machine ? (by_work ? by_work : 1u) : machine), block(64);
     // LOCAL: one queue set per XCD, a path lives and dies on the XCD that started it — records and cold records are handed over through
     // that XCD's L2 with write-back stores.  Fewer shards (tests, experiments): any wave may take any chunk, everything is written through.
@@ -639,7 +652,7 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int si)
 }
 // after the host has synchronised: did a persistent launch leave on its abort word?
 int check_v5_status(de_ctx* c) {
-    for (int i = 0; i < DE_MAX_SLOTS; ++i) {
+    for (int i = 0; i < DE_MAX_SLOTS + 4; ++i) {
         de_ctx::V5State& S = c->v5s[i];
         if (S.h_status && S.h_status[0] != 0u) {
             const uint32_t code = S.h_status[0];
@@ -797,7 +810,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_V2_G", &c->tune_gas, 0); env_int("DE_V2_CHUNK", &c->tune_chunk, 1); env_int("DE_V2_WPC", &c->tune_wpc, 1);
         env_int("DE_V2_MAX_SPP", &c->tune_max_spp, 1);      // test hook: split launches at this many samples per pixel
         if (const char* e3 = getenv("DE_V3_MAX_ITEMS")) { long long x = atoll(e3); if (x >= 4096) c->v3_max_items = (size_t)x; }
-        env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_V3_FUSE_TRACK", &c->v3_fuse_track, 0);
+        env_int("DE_V3_WPC", &c->v3_wpc, 1); env_int("DE_V3_FUSE_TRACK", &c->v3_fuse_track, 0); env_int("DE_V3_FINISHER", &c->v3_finisher, 2); env_int("DE_V5_FIN_WPC", &c->v5_fin_wpc, 1);
         env_int("DE_V3_PIPES", &c->v3_pipes, 1); if (c->v3_pipes > 4) c->v3_pipes = 4;
         env_int("DE_V3_BATCHES", &c->v3_batches, 1);
         env_int("DE_V3_DEPTHS", &c->v3_depths, 1); if (c->v3_depths > 25) c->v3_depths = 25;
@@ -1236,7 +1249,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         const int si = c->next_slot % n_cycle;
         const int pipe = (v3k && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle; c->launch_slot = si;
-        if (v5k) { int rc5 = v5_reserve(c, si, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
+        if (v5k) { int rc5 = v5_reserve(c, si, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
+        if (this_v3 && c->v3_finisher == 5 && c->launch_depths < 25) { int rc5 = v5_reserve(c, DE_MAX_SLOTS + pipe, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
         if (this_v3) {
             // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),
             // and a batch of one sample per pixel that still does not fit runs on the state machine

@@ -51,6 +51,13 @@ struct Args {
     unsigned long long* cold;   // 8 x 8 bytes per path
     uint32_t* status;           // host-visible: [0] abort code (0 = clean)
     uint32_t n_items, pool_chunks, ring_mask, n_shards;
+    // as the FINISHER of the wavefront pipeline (render_kernel_v3.hip): the work items are not fresh samples but the path rays the
+    // pipeline queued for its next vertex round — *resume_count 64-byte records of its sphere-trace queue (holes included) plus the
+    // paths' throughput and radiance in its cold records.  nullptr = start from (pixel, sample).
+    const uint4* resume_rec;
+    const uint32_t* resume_count;
+    const float* resume_cold;        // 16 floats per path: thr, Ls, ...
+    uint32_t resume_capacity;
     uint32_t reserve_chunks;    // new paths are started only while at least this many chunks are free
     uint32_t backlog_target;    // ... and while fewer than this many chunks are queued in the wave's shard: deep queues keep the waves
                                 // in their stages (no scheduler round trips, full chunks), a bounded population keeps them in the caches
@@ -148,6 +155,7 @@ struct Wave {
     uint32_t in_chunk, in_lo, in_hi, in_h, in_n;
     uint32_t in_cells, in_k;    // the cells of the current claim as first read (lane j = cell j; DE_V5_EMPTY = not yet stored), entries read so far
     uint32_t done_local;
+    uint32_t n_work;            // work items of the launch: A.n_items, or the records to resume
     uint32_t w_lo, w_hi;        // work items (new paths) this wave has drawn from the device-wide counter
     uint32_t victim;            // the other team this wave looks at next when its own has nothing
     bool primary_left, aborted;
@@ -363,7 +371,7 @@ struct Wave {
             const uint32_t work_next = (uint32_t)__builtin_amdgcn_readlane(ready, 62);
             const int free_chunks = __builtin_amdgcn_readlane(ready, 63);
             if (STATS) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); stat(ST_T_SNAP, t - tq); tq = t; }
-            if (work_next >= A.n_items && w_lo >= w_hi) primary_left = false;
+            if (work_next >= n_work && w_lo >= w_hi) primary_left = false;
             // the fullest queue, and how much is queued in all
             int best_q = -1, best = 0, backlog = 0;
 #pragma unroll
@@ -406,7 +414,7 @@ struct Wave {
             // nothing to do: whatever this wave still holds may be what the others are waiting for
             if (flush_outs(true)) continue;
             if (done_local) { if (lane_id() == 0) add_agent(ctl(C_DONE), done_local); done_local = 0u; }
-            if (uni(ld_agent(ctl(C_DONE))) >= A.n_items) return Q_EXIT;
+            if (uni(ld_agent(ctl(C_DONE))) >= n_work) return Q_EXIT;
             stat(ST_IDLE, 1);
             // nothing will be started any more and this wave is not one of the closers: make room for the next launch's waves
             if (!primary_left && blockIdx.x >= A.closers && idle >= 32u) return Q_EXIT;
@@ -500,14 +508,37 @@ struct Wave {
             uint32_t w = 0;
             if (lane_id() == 0) w = add_agent(ctl(C_WORK), 256u);
             w = uni(w);
-            if (w >= A.n_items) { primary_left = false; return; }
-            w_lo = w; w_hi = min(w + 256u, A.n_items);
+            if (w >= n_work) { primary_left = false; return; }
+            w_lo = w; w_hi = min(w + 256u, n_work);
         }
         const uint32_t w0 = w_lo;
         w_lo += 64u;
         ensure_stash();
         const uint32_t w = w0 + (uint32_t)lane_id();
         const bool active = w < w_hi;
+        if (A.resume_rec) {
+            // finisher: a queued path ray of the pipeline goes into this launch's sphere-trace queue, its throughput and radiance into
+            // this launch's cold record (everything else of a cold record is rewritten before it is read: the ray starts a vertex)
+            Path p;
+            bool live = false;
+            if (active) {
+                const uint4* r = A.resume_rec + (size_t)w * 4u;
+                const uint4 a0 = r[0], b0 = r[1], c0 = r[2], d0 = r[3];
+                p.pid = a0.x; p.meta = a0.y; p.rng.s0 = a0.z; p.rng.s1 = a0.w; p.rng.draws = 0;
+                p.P = v3(wf::asf(b0.x), wf::asf(b0.y), wf::asf(b0.z)); p.W = v3(wf::asf(b0.w), wf::asf(c0.x), wf::asf(c0.y));
+                p.x[0] = wf::asf(c0.z); p.x[1] = wf::asf(c0.w); p.x[2] = wf::asf(d0.x); p.x[3] = wf::asf(d0.y); p.x[4] = wf::asf(d0.z); p.x[5] = wf::asf(d0.w);
+                live = p.pid != DE_V3_HOLE;
+                if (live) {
+                    const float* cr = A.resume_cold + (size_t)p.pid * 16u;
+                    const ColdWT<LOCAL> cold{A.cold};
+                    cold.set_thr_ls(p.pid, cr[0], cr[1]);
+                }
+            }
+            done_local += (uint32_t)__popcll(__ballot(active && !live));      // holes count as finished work items
+            stat(ST_RECS + NQ, min(64u, w_hi - w0));
+            push<Q_ST>(p, live);
+            return;
+        }
         const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
         Path p;
         int target = -2;
@@ -576,6 +607,7 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
     W.in_ring = 0u; W.in_chunk = DE_V5_NONE; W.in_lo = W.in_hi = W.in_h = W.in_n = 0u; W.in_cells = DE_V5_EMPTY; W.in_k = 0u;
     W.done_local = 0u; W.primary_left = true; W.aborted = false;
     W.w_lo = W.w_hi = 0u; W.victim = W.shard;
+    W.n_work = A.resume_rec ? min(*A.resume_count, A.resume_capacity) : A.n_items;
     __shared__ unsigned long long s_stats[STATS ? 64 : 1];
     if (STATS) s_stats[threadIdx.x & 63u] = 0ull;
     __syncthreads();

@@ -82,6 +82,24 @@ def test_fused_track_kernel_is_the_same_function(Renderer, monkeypatch):
     assert bits_equal_fraction(out[2], out[3]) == 1.0 and bits_equal_fraction(out[2], out[4]) == 1.0 and out[2].max() > 0
 
 
+def test_persistent_scheduler_as_the_pipelines_finisher(Renderer, monkeypatch):
+    """DE_V3_FINISHER=5: the paths the pipeline hands over after its vertex rounds are finished by render_kernel_v5 (resume mode: the
+    queued rays go into its own sphere-trace queue, throughput and radiance into its cold records) instead of render_kernel_v2.
+    Same bits; measured a tie on every camera, so not the default."""
+    monkeypatch.setenv("DE_V3_FINISHER", "5"); monkeypatch.setenv("DE_AUTO_MIN_ITEMS", "0")
+    kw = dict(seed=8, texture_source="synthetic", texture_size=(2048, 1024), cloud_heavy=True)
+    out = {}
+    for variant in (2, 4):
+        r = Renderer((256, 128), (0, 1, 0), **kw)
+        r.set_camera_pos(-9.0e6, 0.0, 9.0e6); r.set_fov(0.3)
+        r.set_kernel_variant(variant)
+        r.accumulate(6); r.accumulate(3)
+        out[variant] = r.fetch_hdr()
+        if variant == 4:
+            assert r.last_call_info()["variant"] == 3 and r.last_call_info()["depths"] < 25
+    assert bits_equal_fraction(out[2], out[4]) == 1.0 and out[2].max() > 0
+
+
 def test_wavefront_pipeline_deep_paths(Renderer):
     """A close look straight down at a cloud-heavy day side: 4.6 vertices per sample on average, 8 % of the samples beyond the
     switch to isotropic cloud scattering after vertex 9, some reaching the 25-vertex limit — many vertex rounds through all ten
