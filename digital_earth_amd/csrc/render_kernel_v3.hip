@@ -646,7 +646,10 @@ struct StStage {
     float land_height_scale, escape_r, max_ray_dist;
     float t; int cnt;
     DE_DEV void begin(wf::Path& p) { t = p.x[0]; cnt = 0; }
-    DE_DEV bool step(wf::Path& p) {
+    // A step in two halves — `issue` up to the map tap's load, `resolve` from the texel on — so that a caller holding two records per lane
+    // can have both loads in flight before it consumes either (render_kernel_v5.hip: run_loop2).  step() = the two in a row.
+    struct Tok { uint32_t q; float fx, fy, len; };
+    DE_DEV bool issue(wf::Path& p, Tok& k) {                                 // true: the record ended in this half (escaped ray)
         const vec3 Q = p.P + p.W * t;
         const float len = length_nr(Q);
         if (cnt <= 100) {                                                    // escaped ray: see render_kernel_v2.hip
@@ -656,12 +659,18 @@ struct StStage {
         }
         const vec3 n = Q * de_rcp_nr(len);
         const vec2_ uv = sphere_UV_map(n);
-        const float tex = tap_r8<CLAMP>(topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
-        const float sdf = len - DE_PLANET_R - land_height_scale * tex;
+        k.q = tap_r8_issue<CLAMP>(topo, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &k.fx, &k.fy);
+        k.len = len;
+        return false;
+    }
+    DE_DEV bool resolve(wf::Path&, const Tok& k) {
+        const float tex = tap_r8_finish(k.q, k.fx, k.fy);
+        const float sdf = k.len - DE_PLANET_R - land_height_scale * tex;
         t += sdf;
         cnt++;
         return t > max_ray_dist || de_abs(sdf) < t * 0.0001f || cnt >= 250;
     }
+    DE_DEV bool step(wf::Path& p) { Tok k; return issue(p, k) || resolve(p, k); }
     DE_DEV int finish(wf::Path& p) { return wf::after_sphere_trace(p, t, max_ray_dist); }
 };
 template <bool CLAMP>
@@ -773,25 +782,33 @@ struct CloudStage {
         C = p.P + t * p.W;
         trn = 1.0f; cloud_event = 0;
     }
-    DE_DEV bool step(wf::Path& p) {
+    // issue / resolve: as in StStage (the draws keep their order: free flight in `issue`; collision test and event in `resolve`)
+    struct Tok { uint32_t q; float fx, fy, h; bool shell; };
+    DE_DEV bool issue(wf::Path& p, Tok& k) {                                 // true: the segment ended without a further point
         const float neg_log = -de_log_unit(rng_next(p.rng));
         const float t_step = neg_log * rmaxc;
         C = C + t_step * p.W;
         t += t_step;
         if (t >= tmax) return true;
         const float len = length_nr(C);
-        float density = 0.0f;
-        if (len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER) {
+        k.shell = len > DE_CLOUDS_LOWER && len < DE_CLOUDS_UPPER;
+        if (k.shell) {
             const vec3 nrm = C * de_rcp_nr(len);
             const vec2_ uv = sphere_UV_map(nrm);
 #ifndef DE_NO_TAP_REUSE
-            float fx, fy;
-            const uint32_t q = tap_r8_issue_cached<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &fx, &fy, last_idx, last_q);
-            const float tex = tap_r8_finish(q, fx, fy);
+            k.q = tap_r8_issue_cached<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &k.fx, &k.fy, last_idx, last_q);
 #else
-            const float tex = tap_r8<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f));
+            k.q = tap_r8_issue<CLAMP>(clouds, fract_(uv.x * 1.0f), fract_(uv.y * 1.0f), &k.fx, &k.fy);
 #endif
-            const float h = (len - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
+            k.h = (len - DE_CLOUDS_LOWER) * (1.0f / DE_CLOUDS_THICKNESS);
+        }
+        return false;
+    }
+    DE_DEV bool resolve(wf::Path& p, const Tok& k) {
+        float density = 0.0f;
+        if (k.shell) {
+            const float tex = tap_r8_finish(k.q, k.fx, k.fy);
+            const float h = k.h;
             const float split = 0.2f;
             density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
         }
@@ -805,6 +822,7 @@ struct CloudStage {
         }
         return !(t < tmax);
     }
+    DE_DEV bool step(wf::Path& p) { Tok k; return issue(p, k) || resolve(p, k); }
     DE_DEV int finish(wf::Path& p) {
         const float aux = p.x[2], X = p.x[3];
         if (kind == 0) {

@@ -67,6 +67,9 @@ struct Args {
     uint32_t idle_limit;        // watchdog: scheduler rounds without work before a wave raises the abort word
 };
 template <int... T> struct Targets {};
+#ifndef DE_V5_DUAL
+#define DE_V5_DUAL 0           // experiment: bit 0 = the sphere-trace stage holds two records per lane (run_loop2), bit 1 = the cloud stage
+#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define DE_V5_SC1 16            // aux bits of the raw buffer builtins on gfx950: 16 = sc1 (write-through / L1 bypass)
@@ -479,6 +482,69 @@ struct Wave {
         leave_input();
     }
 
+#if DE_V5_DUAL
+    // ---- (experiment, off: profiles/experiments/README.md) a loop stage with TWO records per lane.  A single-class wave has one dependent load per trip (the map tap) and nothing else to
+    // issue while it is in flight; four such waves per SIMD do not cover it (58 % of the wave-cycles were waits).  Here a lane holds two
+    // records, A and B; a trip issues A's load, then B's, and only then consumes either: two loads in flight per lane, the address
+    // arithmetic of B under A's latency.  Each slot is serviced exactly like run_loop's one (own thresholds, shared input cursor).
+    template <int Q, int SERVICE, typename Stage, int... TARGETS>
+    DE_DEV void run_loop2(Stage& sa, Stage& sb, Targets<TARGETS...>) {
+        Path pa, pb;
+        bool busy_a = false, busy_b = false, fin_a = false, fin_b = false;
+        int tgt_a = -1, tgt_b = -1;
+        bool dry = false;
+        uint32_t trips = 0, retry_at = 0, services = 0;
+        auto service = [&](Path& p, Stage& st, bool& busy, bool& fin, int target, bool refill) {
+            const unsigned long long ts0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            ensure_stash();
+            (push<TARGETS>(p, fin && target == TARGETS), ...);
+            fin = false;
+            if (STATS) stat(ST_T_PUSH, __builtin_amdgcn_s_memrealtime() - ts0);
+            if (refill) {
+                dry = false;
+                bool got = false;
+                uint32_t idx = 0;
+                for (;;) {
+                    const unsigned long long m_need = __ballot(!busy && !got);
+                    if (m_need == 0ull) break;
+                    const uint32_t avail = in_hi - in_lo;
+                    if (avail == 0u) {
+                        if (!next_input()) { dry = true; retry_at = trips + 24u; stat(ST_DRY, 1); break; }
+                        continue;
+                    }
+                    const uint32_t my = (uint32_t)__popcll(m_need & ((1ull << lane_id()) - 1ull));
+                    if (!busy && !got && my < avail) { idx = in_chunk * DE_V5_CH + in_lo + my; got = true; }
+                    const uint32_t take = min((uint32_t)__popcll(m_need), avail);
+                    in_lo += take;
+                    stat(ST_RECS + Q, take);
+                }
+                if (got) { load_rec(rs, idx, p); st.begin(p); busy = true; }
+            }
+            if (STATS) stat(ST_T_SERVICE, __builtin_amdgcn_s_memrealtime() - ts0);
+            if ((++services & 31u) == 0u) flush_outs(false);
+        };
+        for (;;) {
+            const int na = __popcll(__ballot(busy_a)), nb = __popcll(__ballot(busy_b));
+            const bool none = na + nb == 0;
+            const bool may_refill = !dry || none || (na + nb >= 32 && trips >= retry_at);
+            if (none || (64 - na >= SERVICE && (may_refill || __ballot(fin_a) != 0ull))) service(pa, sa, busy_a, fin_a, tgt_a, may_refill);
+            if (none || (64 - nb >= SERVICE && ((may_refill && !dry) || __ballot(fin_b) != 0ull))) service(pb, sb, busy_b, fin_b, tgt_b, may_refill && !dry);
+            if (__ballot(busy_a || busy_b) == 0ull) { if (dry || aborted) break; else continue; }
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, (unsigned long long)(__popcll(__ballot(busy_a)) + __popcll(__ballot(busy_b)))); }
+            typename Stage::Tok ka, kb;
+            bool da = false, db = false;
+            if (busy_a) da = sa.issue(pa, ka);
+            if (busy_b) db = sb.issue(pb, kb);
+            if (busy_a && !da) da = sa.resolve(pa, ka);
+            if (busy_b && !db) db = sb.resolve(pb, kb);
+            if (da) { tgt_a = sa.finish(pa); busy_a = false; fin_a = true; }
+            if (db) { tgt_b = sb.finish(pb); busy_b = false; fin_b = true; }
+            trips++;
+        }
+        leave_input();
+    }
+#endif
+
     // ---- a straight-line stage: one record per lane, chunk after chunk
     template <int Q, typename Body, int... TARGETS>
     DE_DEV void run_flat(Body body, Targets<TARGETS...>) {
@@ -625,7 +691,12 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
         switch (s) {
         case Q_ST: {
             StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+#if DE_V5_DUAL & 1
+            StStage<CLAMP> st2 = st;
+            W.template run_loop2<Q_ST, DE_V5_SVC_ST>(st, st2, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+#else
             W.template run_loop<Q_ST, DE_V5_SVC_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+#endif
             W.template mark<Q_ST>();
         } break;
         case Q_GAS: {
@@ -635,7 +706,12 @@ __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, con
         } break;
         case Q_CLOUD: {
             CloudStage<CLAMP> st{a.clouds};
+#if DE_V5_DUAL & 2
+            CloudStage<CLAMP> st2{a.clouds};
+            W.template run_loop2<Q_CLOUD, DE_V5_SVC_CLOUD>(st, st2, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+#else
             W.template run_loop<Q_CLOUD, DE_V5_SVC_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+#endif
             W.template mark<Q_CLOUD>();
         } break;
         case Q_EVENT:
