@@ -442,16 +442,19 @@ def main():
                          "bit_identical_fraction_pipeline_kernels": float((g3 == c).mean()),
                          "note": "vs oracle/ (the build's CPU restatement, itself held to the reference's executed text by tests/test_ref_fixtures.py; Taichi-internal arithmetic is defined, not pinned: DESIGN §2)"}
         out["speedup_vs_cpu_port"] = value / base["value"]
-    if world > 1 and backend == "nccl" and args.reduce == "torch" and args.check_spp > 0 and not os.environ.get("DE_NO_LIB_LEG"):
+    if world > 1 and (backend == "nccl" or os.environ.get("DE_FORCE_LIB_LEG")) and args.reduce == "torch" and args.check_spp > 0 and not os.environ.get("DE_NO_LIB_LEG"):
         # The library's own communicator (de_comm_init / de_reduce: RCCL bound with dlopen, ncclCommInitRank declared by hand) has
         # never run between two GPUs on the builder's box: give it ONE untimed frame here, after everything that is measured, and
         # report whether its assembled frame equals the torch.distributed one bit for bit.  A watchdog prints the line without it
         # if the leg hangs: the measurement is never hostage to this check.
         import threading
 
+        printed = []
+
         def bail():
-            if rank == 0:
-                out["lib_reduce"] = {"error": "timed out after 120 s"}
+            # this rank (or a peer it waits for) hangs in the leg, or in the barrier after it: the line goes out once, then the process ends
+            if rank == 0 and not printed:
+                out.setdefault("lib_reduce", {"error": "timed out after 120 s"})
                 print(json.dumps(out), flush=True)
             os._exit(0)
         dog = threading.Timer(120.0, bail)
@@ -482,7 +485,15 @@ def main():
             lf.close()
         except Exception as exc:          # noqa: BLE001 - reported, not swallowed
             out["lib_reduce"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+            printed.append(True)
+        dist.barrier()                    # still under the watchdog: a peer that died in the leg must not hang this rank
+        for f in frames:
+            f.close()
+        dist.destroy_process_group()
         dog.cancel()
+        return
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

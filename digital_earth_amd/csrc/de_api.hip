@@ -1574,7 +1574,7 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
         // only the root receives the assembled frame: elsewhere ncclReduce leaves recvbuff alone, and the display / fetch entry
         // points keep reading the rank's own sums
         int my_rank = c->comm_rank;
-        if (comm) { if (!g_rccl.CommUserRank || g_rccl.CommUserRank(use, &my_rank) != 0) my_rank = -1; }
+        if (comm) { if (!g_rccl.CommUserRank || g_rccl.CommUserRank(use, &my_rank) != 0) my_rank = root; }      // cannot ask: behave as every rank did before (the root is right, the others show scratch)
         if (my_rank == root) c->display_src = c->d_assembled;
     }
     return DE_OK;

@@ -119,6 +119,23 @@ def test_library_communicator_refuses_two_ranks_on_one_gpu_cleanly():
     assert "ncclCommInitRank" in text or "libdigitalearth_hip error" in text, text[-3000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_in_library_reduce_leg_reports_instead_of_hanging(tmp_path):
+    """bench.py --gpus N gives the library's own communicator one untimed frame after the measurement (round 4) and reports it as
+    `lib_reduce`.  Two ranks on ONE device: RCCL refuses the communicator — the leg must turn that into an `error` entry of the line (the
+    measurement intact, exit code 0), not into a hang or a lost line.  Between two GPUs the same leg reports bit_identical_fraction."""
+    port = 29500 + (os.getpid() % 400)
+    p = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "2"] + COMMON,
+             env_extra={"DE_DIST_BACKEND": "gloo", "DE_FORCE_LIB_LEG": "1"}, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    j = _json_line(p.stdout)
+    assert j["value"] > 0 and j["multi_gpu_parity"]["bit_identical_fraction"] == 1.0
+    assert "lib_reduce" in j and ("error" in j["lib_reduce"] or j["lib_reduce"].get("bit_identical_fraction") == 1.0), j.get("lib_reduce")
+    assert all("kernel" in pr for pr in j["per_rank"]) and j["config"]["primed_frames"] == 4
+
+
 def _visible_gpus():
     """Counted in a child process: this pytest process must not load torch's HIP runtime before the library's own."""
     try:
