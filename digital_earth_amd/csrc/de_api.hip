@@ -281,6 +281,7 @@ struct de_ctx {
     // overlap; large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay
     // with the state machine and its launch slots.
     int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
+    int auto_lone_v5 = 1;            // 1: a small call that finds nothing of this context in flight runs the persistent scheduler (env DE_AUTO_LONE_V5)
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
     // views whose paths are long (limb views through thick cloud: 2.4 - 2.9 ns of GPU time per path against 1.0 - 1.4 for the default camera)
     // keep the stage kernels full for more rounds and amortise a third, smaller batch: the pipeline then runs auto_deep_depths
@@ -817,7 +818,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
-        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1);
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -1186,8 +1187,19 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             else pipeline = false;
         }
     }
-    const bool v5k = c->kernel_variant == 5 && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
-    const int base_variant = c->kernel_variant == 4 ? 2 : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
+    // The automatic variant's small calls (below auto_min_items: the reference's interactive loop is accumulate() x 1 then fetch_image(),
+    // earth_viewer.py:241-243).  A call that finds NO launch of this context in flight — the host has fetched / synchronised since the
+    // last one: every frame of that loop — is alone on the GPU and its latency is what the user sees: the persistent stage scheduler ends
+    // such a call 20 % sooner than the state machine (1920x1080 x 1 spp + fetch_image: 16.9 against 21.3 ms; a launch of the state machine
+    // cannot be shorter than its longest path in ONE lane, the scheduler's paths hop between waves that are all busy).  Calls issued
+    // while others are in flight overlap through the launch slots, which the state machine does better (64 x 1 spp: 295 against 523 ms).
+    bool lone_small = false;
+    if (c->kernel_variant == 4 && c->auto_lone_v5 && v2 && !c->count && !pipeline && call_items >= (1ull << 18) && call_items < c->auto_min_items) {
+        lone_small = true;
+        for (int i = 0; i < c->n_slots; ++i) lone_small = lone_small && !c->slot[i].pending;
+    }
+    const bool v5k = (c->kernel_variant == 5 || lone_small) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
+    const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
@@ -1246,7 +1258,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         // pipeline launches cycle through the call's pipes (one launch slot each)
         const int n_cycle_want = v3k ? pipes : ((need_bytes > ((size_t)96 << 20)) ? (c->big_slots < c->n_slots ? c->big_slots : c->n_slots) : c->n_slots);
         const int n_cycle = n_cycle_want < c->n_slots ? n_cycle_want : c->n_slots;      // never a slot the context stream does not join
-        const int si = c->next_slot % n_cycle;
+        const int si = lone_small ? 0 : c->next_slot % n_cycle;      // a lone small call keeps ONE slot's pool and rings warm
         const int pipe = (v3k && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle; c->launch_slot = si;
         if (v5k) { int rc5 = v5_reserve(c, si, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }

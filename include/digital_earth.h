@@ -210,7 +210,9 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *                batches side by side) and the surviving paths finish in the state machine (variant 2).  Large = more than 96 M
  *                paths: always (two batches; views with long paths — GPU time per path of EARLIER calls, read without waiting —
  *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the pipeline on four
- *                pipes.  Smaller calls run variant 2 alone, overlapping through the launch slots.  The choices move time, never bits
+ *                pipes.  Smaller calls run variant 2 alone, overlapping through the launch slots — except a call of 2^18 .. 2^23 paths that
+ *                finds nothing of this context in flight (accumulate(1) then fetch_image(), frame after frame): variant 5, for its
+ *                latency.  The choices depend on the call's size and on what is in flight, never on a timing; they move time, never bits
  *   2            wave-level state machine only (render_kernel_v2.hip)
  *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
  *   1            per-lane loops (render_kernel.hip)

@@ -38,6 +38,14 @@ for spp, total in ((1, 16), (4, 16), (1, 64), (4, 64), (16, 64)):
     print("accumulate(%d) x %d: %.1f ms = %.0f Msamples/s, %.2fx the time of accumulate(%d)" % (spp, n, ms, W * H * total / ms / 1e3, ms / base[total], total))
 t0 = time.perf_counter(); r.reset_framebuffer(); r.accumulate(1); img = r.fetch_image(); t1 = time.perf_counter()
 print("reset + accumulate(1) + fetch_image (host copy): %.2f ms" % ((t1 - t0) * 1e3))
+# the reference's window loop (earth_viewer.py:241-243, 316-317): accumulate() x 1, then fetch_image(), frame after frame
+for _ in range(3):
+    r.accumulate(1); r.fetch_image()
+t0 = time.perf_counter()
+for _ in range(30):
+    r.accumulate(1); img = r.fetch_image()
+t1 = time.perf_counter()
+print("interactive loop, accumulate(1) + fetch_image per frame: %.2f ms (%s)" % ((t1 - t0) * 1e3 / 30, r.last_call_info()["kernel"]))
 if "--check" in sys.argv:
     r.reset_framebuffer(); r.accumulate(16); a = r.fetch_hdr()
     r.reset_framebuffer()
