@@ -1197,6 +1197,10 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     if (c->kernel_variant == 4 && c->auto_lone_v5 && v2 && !c->count && !pipeline && call_items >= (1ull << 18) && call_items < c->auto_min_items) {
         lone_small = true;
         for (int i = 0; i < c->n_slots; ++i) lone_small = lone_small && !c->slot[i].pending;
+        if (c->mem_budget) {      // its pool, rings and cold records must fit the budget (one slot): otherwise the state machine, which needs none
+            const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
+            if (fixed + call_items * 64ull > (unsigned long long)c->mem_budget) lone_small = false;
+        }
     }
     const bool v5k = (c->kernel_variant == 5 || lone_small) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
@@ -1222,7 +1226,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         }
         if (v5k) {   // 64 B of cold record per path of a launch
             unsigned long long max5 = (unsigned long long)c->v5_max_items;
-            if (c->mem_budget) {      // three launch slots in flight, each: the chunk pool + rings, and 64 B of cold record per path
+            if (c->mem_budget && !lone_small) {      // three launch slots in flight, each: the chunk pool + rings, and 64 B of cold record per path
                 const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
                 const unsigned long long share = (unsigned long long)c->mem_budget / 3ull;
                 const unsigned long long fit = share > fixed ? (share - fixed) / 64ull : 0ull;
