@@ -262,8 +262,8 @@ struct de_ctx {
     } v5s[DE_MAX_SLOTS + 4];         // one per launch slot (kernel variant 5), then one per pipe (the pipeline's finisher, v3_finisher = 5)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
-    int v5_local = 0;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
-    int v5_backlog = 4;              // chunks per wave queued in a shard before the waves stop starting new paths (env DE_V5_BACKLOG)
+    int v5_local = 1;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
+    int v5_backlog = 2;              // chunks per wave queued in a shard before the waves stop starting new paths (env DE_V5_BACKLOG)
     int v5_pool_log2 = 18;           // chunks of 64 records in a slot's pool (2^18 = 1 GB; env DE_V5_POOL_LOG2)
     int v5_claim_k = 16, v5_age = 20000, v5_closers_per_cu = 2, v5_stats = 0;   // env DE_V5_CLAIM_K / _AGE (10 ns ticks) / _CLOSERS / _STATS
     int v5_reserve_pct = 25;         // new paths start only while this share of the pool is free (env DE_V5_RESERVE_PCT)
