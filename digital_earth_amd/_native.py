@@ -94,7 +94,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 3   # DE_ABI_VERSION of include/digital_earth.h
+ABI_VERSION = 4   # DE_ABI_VERSION of include/digital_earth.h
 
 
 class NativeLibraryError(RuntimeError):

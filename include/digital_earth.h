@@ -25,8 +25,9 @@ extern "C" {
 
 /* 1: round 1.  2: round 2 (contract-2 arithmetic, de_share_textures / de_trim_textures / de_comm_* added, DE_FLAG_NO_FAST_DIVISION
  * retired) — shipped still reporting 1.  3: launch slots (de_flush), de_use_own_stream, de_set_stream(NULL) = the null stream,
- * loans recorded by de_share_textures. */
-#define DE_ABI_VERSION 3
+ * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_debug_v5_stats,
+ * kernel variant 5. */
+#define DE_ABI_VERSION 4
 /* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
 #define DE_ARITHMETIC_CONTRACT 2
 
