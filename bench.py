@@ -265,6 +265,7 @@ def main():
     for i in range(args.warmup):
         step(frames[i % len(frames)])
     elapsed = timed(args.steps)
+    timed_info = frames[(args.steps - 1) % len(frames)].r.last_call_info()      # what the calls of the timed region ran (a lone call may run differently)
     last = frames[(args.steps - 1) % len(frames)]
     if args.dump_hdr and rank == 0:
         np.save(args.dump_hdr, last.r.fetch_hdr())
@@ -303,7 +304,7 @@ def main():
         elapsed, avg_kernel_ms, single_frame_ms, alt["elapsed_s"] = (float(x) for x in t.tolist())
         # what every rank measured on its own (HIP events): render launch, collective; and the tiles it owns
         per_rank = [None] * world
-        info = r.last_call_info()
+        info = timed_info
         dist.all_gather_object(per_rank, {"rank": rank, "render_ms": my_render_ms, "reduce_ms": my_reduce_ms,
                                           "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank]),
                                           "kernel": info["kernel"], "launches_per_call": info["launches"]})
@@ -382,13 +383,13 @@ def main():
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
                    "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
                    "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3, "waves_per_cu": wpc, "primed_frames": n_prime,
-                   "kernel": r.last_call_info()["kernel"],
+                   "kernel": timed_info["kernel"], "launches_per_call": timed_info["launches"],
                    "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": ("de_accumulate(%d): kernel variant %s — %s; "
-                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), r.last_call_info()["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
+                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), timed_info["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
                      "note": "the path is VALU-issue / divergence bound, not HBM bound (SURVEY §8d): see valu"},
         "valu": {"unit": "see fields", "loop_steps_per_sample": steps_per_sample,
