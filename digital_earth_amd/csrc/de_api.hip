@@ -283,6 +283,10 @@ struct de_ctx {
     // with the state machine and its launch slots.
     int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
     int auto_mid_batches1 = 1;       // 1: a mid-size call issued while others are in flight is one batch on one pipe (env DE_AUTO_MID_BATCHES1)
+    unsigned long long auto_lone_max_items = 1ull << 23;    // largest lone call that runs the persistent scheduler (env DE_AUTO_LONE_MAX_ITEMS): the small calls.
+                                                            // Up to 40 M paths it would still win on latency (a lone 1/8 share 34.2 against 43.7 ms, 1/4 share 56.0 / 65.1), but the
+                                                            // first call of every back-to-back run is a lone one, and a persistent launch ahead of pipeline launches cost such runs
+                                                            // 3-8 % (12 steps of the 1/4 share: 46.2 against 42.8 ms per step): not by default
     int auto_lone_v5 = 1;            // 1: a small call that finds nothing of this context in flight runs the persistent scheduler (env DE_AUTO_LONE_V5)
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
     // views whose paths are long (limb views through thick cloud: 2.4 - 2.9 ns of GPU time per path against 1.0 - 1.4 for the default camera)
@@ -833,6 +837,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
+        if (const char* e8 = getenv("DE_AUTO_LONE_MAX_ITEMS")) { long long x = atoll(e8); if (x >= 0) c->auto_lone_max_items = (unsigned long long)x; }
         if (const char* e4 = getenv("DE_AUTO_MIN_ITEMS")) { long long x = atoll(e4); if (x >= 0) c->auto_min_items = (unsigned long long)x; }
         env_int("DE_V3_WPC_ST", &c->v3_wpc_class[0], 1); env_int("DE_V3_WPC_GAS", &c->v3_wpc_class[1], 1);
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
@@ -1207,19 +1212,20 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             else pipeline = false;
         }
     }
-    // The automatic variant's small calls (below auto_min_items: the reference's interactive loop is accumulate() x 1 then fetch_image(),
-    // earth_viewer.py:241-243).  A call that finds NO launch of this context in flight — the host has fetched / synchronised since the
-    // last one: every frame of that loop — is alone on the GPU and its latency is what the user sees: the persistent stage scheduler ends
-    // such a call 20 % sooner than the state machine (1920x1080 x 1 spp + fetch_image: 16.9 against 21.3 ms; a launch of the state machine
-    // cannot be shorter than its longest path in ONE lane, the scheduler's paths hop between waves that are all busy).  Calls issued
-    // while others are in flight overlap through the launch slots, which the state machine does better (64 x 1 spp: 295 against 523 ms).
+    // The automatic variant's LONE calls.  A call that finds NO launch of this context in flight — the host has fetched / synchronised
+    // since the last one: every frame of the reference's window loop, accumulate() x 1 then fetch_image() (earth_viewer.py:241-243), or a
+    // progressive render that displays after every call — is alone on the GPU and its latency is what the user sees.  The persistent stage
+    // scheduler ends a small such call sooner than the state machine: 1920x1080 x 1 spp + fetch_image 14.7 against 20.4 ms (a launch of the
+    // state machine cannot be shorter than its longest path in ONE lane; the scheduler's paths hop between waves that are all busy).  Calls
+    // issued while others are in flight overlap through the launch slots on the state machine (64 x 1 spp: 295 against 523 ms).
     bool lone_small = false;
-    if (c->kernel_variant == 4 && c->auto_lone_v5 && v2 && !c->count && !pipeline && call_items >= (1ull << 18) && call_items < c->auto_min_items) {
+    if (c->kernel_variant == 4 && c->auto_lone_v5 && v2 && !c->count && call_items >= (1ull << 18) && call_items <= c->auto_lone_max_items) {
         lone_small = !launches_in_flight(c);
         if (c->mem_budget) {      // its pool, rings and cold records must fit the budget (one slot): otherwise the state machine, which needs none
             const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
             if (fixed + call_items * 64ull > (unsigned long long)c->mem_budget) lone_small = false;
         }
+        if (lone_small) pipeline = false;
     }
     const bool v5k = (c->kernel_variant == 5 || lone_small) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
