@@ -273,6 +273,7 @@ struct de_ctx {
     int launch_variant = 2;          // variant of the sub-launch being issued
     int launch_pipe = 0;             // v3 pipe of the sub-launch being issued
     int launch_slot = 0;             // launch slot of the sub-launch being issued
+    bool launch_one_batch = false;   // the call being issued is one batch on one pipe (calls in flight)
     int last_call[4] = {0, 0, 0, 0}; // what the last de_accumulate ran: variant, pipes, pipeline rounds, launches (de_last_call_info)
     int launch_pipes = 1;            // pipes the call being issued runs side by side
     int launch_depths = 25, launch_wpc = 14;   // pipeline settings of the call being issued
@@ -282,6 +283,7 @@ struct de_ctx {
     // overlap; large ones: the L2 holds two batches' lines, not four); launches under 8 M paths (the interactive 1-spp call) stay
     // with the state machine and its launch slots.
     int auto_depths = 3, auto_wpc = 8, auto_pipes = 0;
+    int auto_full_batches1 = 1;      // 1: a full-frame call issued while others are in flight, outside the deep setting, is one batch (env DE_AUTO_FULL_BATCHES1)
     int auto_mid_batches1 = 1;       // 1: a mid-size call issued while others are in flight is one batch on one pipe (env DE_AUTO_MID_BATCHES1)
     unsigned long long auto_lone_max_items = 1ull << 23;    // largest lone call that runs the persistent scheduler (env DE_AUTO_LONE_MAX_ITEMS): the small calls.
                                                             // Up to 40 M paths it would still win on latency (a lone 1/8 share 34.2 against 43.7 ms, 1/4 share 56.0 / 65.1), but the
@@ -459,22 +461,25 @@ static const int V3_NO_MEMORY = 1000;
 int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     de_ctx::V3Pipe& P = c->v3p[pipe];
     if (n_items <= P.capacity) return DE_OK;
-    { int rc = sync_all(c); if (rc) return rc; }
-    for (int i = 0; i < wf::NQ; ++i) { if (P.rec[i]) hipFree(P.rec[i]); P.rec[i] = nullptr; }
-    if (P.cold) hipFree(P.cold);
-    P.cold = nullptr; P.capacity = 0;
     // room for every path plus the holes the waves' last bulk reservations leave (render_kernel_v3.hip: push / close_out)
     const size_t slack = 4u * (size_t)c->n_cus * (size_t)c->v3_slack_wpc * DE_V3_BULK;   // up to 3 producing launches fill a queue before it is drained
-    // 512 B per path: ask first — other contexts, the host framework and the next pipe want memory too (8 GB stay free)
+    // 512 B per path: ask first — other contexts, the host framework and the next pipe want memory too (8 GB stay free) — and BEFORE
+    // giving up what the pipe holds: a request that cannot be met must leave the pipe as it is (the caller then asks for less, which the
+    // pipe may already hold; freeing first made every such call re-allocate its queues: 1 s per frame under a binding budget)
     size_t free_b = 0, total_b = 0;
     const size_t need_b = (size_t)wf::NQ * (n_items + slack) * sizeof(wf::Rec) + n_items * sizeof(wf::Cold);
+    const size_t held_b = P.capacity ? (size_t)wf::NQ * (P.capacity + slack) * sizeof(wf::Rec) + P.capacity * sizeof(wf::Cold) : 0;
     if (c->mem_budget) {
         // the call's pipes run side by side and are sized alike: each gets its share of the budget
         const size_t share = c->mem_budget / (size_t)(c->launch_pipes > 0 ? c->launch_pipes : 1);
         if (need_b > share) return V3_NO_MEMORY;
     }
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need_b + ((size_t)8 << 30)) return V3_NO_MEMORY;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + held_b < need_b + ((size_t)8 << 30)) return V3_NO_MEMORY;
     if (c->v3_test_budget && n_items > c->v3_test_budget) return V3_NO_MEMORY;      // tests: pretend larger queues do not fit
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int i = 0; i < wf::NQ; ++i) { if (P.rec[i]) hipFree(P.rec[i]); P.rec[i] = nullptr; }
+    if (P.cold) hipFree(P.cold);
+    P.cold = nullptr; P.capacity = 0;
     bool ok = true;
     for (int i = 0; i < wf::NQ && ok; ++i) ok = hipMalloc(&P.rec[i], (n_items + slack) * sizeof(wf::Rec)) == hipSuccess;
     if (ok) ok = hipMalloc(&P.cold, n_items * sizeof(wf::Cold)) == hipSuccess;
@@ -539,7 +544,9 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
     // (resume mode): the wavefront stages are at their best while the rays are many and coherent, the megakernel when they
     // are few, deep and divergent — every pipeline launch ends with its own tail, the megakernel has one.
     const int n_depths = c->launch_depths;
-    const bool timed = P.h_round2 && !P.stat_pending && n_depths < 25;
+    // (launches of a call issued as ONE batch overlap other calls' launches: their duration says nothing about the view — the statistic
+    // behind the deep setting is taken from calls with batches side by side only)
+    const bool timed = P.h_round2 && !P.stat_pending && n_depths < 25 && !c->launch_one_batch;
     if (timed) hipEventRecord(P.ev_t[0], stream);
     auto note_round2 = [&]() {      // the ST queue's current set holds the count of round 2's path rays until that queue has been drained twice more
         if (!P.h_round2 || P.stat_pending) return;
@@ -833,7 +840,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
-        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0);
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0); env_int("DE_AUTO_FULL_BATCHES1", &c->auto_full_batches1, 0);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -1186,6 +1193,14 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (c->auto_deep && pipes == 2 && c->auto_deep_depths > c->auto_depths) {
                 c->launch_depths = c->auto_deep_depths;
                 if (c->auto_pipes <= 0 && c->auto_deep_pipes >= 2) { pipes = c->auto_deep_pipes; if (batches < pipes) batches = pipes; }
+            } else if (two_pipe_size && c->auto_pipes <= 0 && c->auto_full_batches1 && launches_in_flight(c)) {
+                // frames back to back on a view that is not in the deep setting: the whole call as ONE batch, consecutive calls on the two
+                // pipes — half the stage launches (and their tails) per frame, the overlap comes from the caller.  1920x1080x64 spp, ms per
+                // step: default camera 171.4 -> 160.8, florida 200.3 -> 195.7, Apollo 108.4 -> 100.3 (three / four pipes: 158.7 / 153.2, for
+                // 68 GB of queues each); sunset hurricane 353.7 -> 369.5, which is why the deep setting keeps its batches.  A lone call
+                // keeps two batches (173 ms against 208).  The queues grow to the whole call the first time this happens (68 GB per pipe for
+                // this frame; when the device or the memory budget has no room the batch is halved as always).
+                batches = 1;
             }
         }
         if (c->trace)
@@ -1230,6 +1245,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     const bool v5k = (c->kernel_variant == 5 || lone_small) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
+    c->launch_one_batch = v3k && batches == 1 && pipes >= 2;
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
     // recovered with a 2^40 magic multiplication (exact while n_tiles*spp^2 < 2^40), and each item owns 8 bytes of the
     // contribution buffer (kept <= 4 GB).  Larger requests are split here; the sample index continues from launch to launch
