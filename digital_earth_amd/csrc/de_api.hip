@@ -289,6 +289,7 @@ struct de_ctx {
                                                             // Up to 40 M paths it would still win on latency (a lone 1/8 share 34.2 against 43.7 ms, 1/4 share 56.0 / 65.1), but the
                                                             // first call of every back-to-back run is a lone one, and a persistent launch ahead of pipeline launches cost such runs
                                                             // 3-8 % (12 steps of the 1/4 share: 46.2 against 42.8 ms per step): not by default
+    int auto_budget_v5 = 1;          // 1: a call the memory budget keeps off the pipeline runs the persistent scheduler when that fits (env DE_AUTO_BUDGET_V5)
     int auto_lone_v5 = 1;            // 1: a small call that finds nothing of this context in flight runs the persistent scheduler (env DE_AUTO_LONE_V5)
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
     // views whose paths are long (limb views through thick cloud: 2.4 - 2.9 ns of GPU time per path against 1.0 - 1.4 for the default camera)
@@ -840,7 +841,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
-        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0); env_int("DE_AUTO_FULL_BATCHES1", &c->auto_full_batches1, 0);
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_BUDGET_V5", &c->auto_budget_v5, 0); env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0); env_int("DE_AUTO_FULL_BATCHES1", &c->auto_full_batches1, 0);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -1207,6 +1208,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             fprintf(stderr, "[de] auto: %llu paths; pipeline launch %.2f ns per path (round-2 ratio %.3f): %s, depths %d pipes %d batches %d\n",
                     call_items, c->auto_ns_per_path, c->auto_ratio, pipeline ? "pipeline" : "state machine", c->launch_depths, pipes, batches);
     }
+    size_t budget_fit = 0;           // paths per pipeline launch the memory budget allows (0: no budget)
+    bool budget_v5 = false;          // the budget has no room for the pipeline: the persistent stage scheduler takes the call
     if (pipeline && c->mem_budget && a.n_tiles > 0) {
         // A budget that is binding — a pipe's share holds less than the batch the call would use — cuts the call into more, smaller
         // launches, each with its own tails.  Measured (profiles/memory_budget.md): batches under ~24 M paths lose to the state
@@ -1226,6 +1229,15 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (pipes > 2 && fit_of(2) >= floor_items) { pipes = 2; if (batches > 2) batches = 2; }
             else pipeline = false;
         }
+        if (pipeline) budget_fit = fit_of(pipes);
+        else if (c->kernel_variant == 4 && c->auto_budget_v5 && v2 && !c->count) {
+            // No room for the pipeline's queues: the persistent stage scheduler needs a fixed pool and 64 B per path instead of 512, and
+            // ends the frame sooner than the state machine on every camera measured (1920x1080x64 spp: 186 / 254 / 491 / 138 ms against
+            // 211 / 305 / 685 / 170) — when at least a quarter of the call fits one of its three launch slots.
+            const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
+            const unsigned long long share = (unsigned long long)c->mem_budget / 3ull;
+            budget_v5 = share > fixed && (share - fixed) / 64ull >= call_items / 4ull;
+        }
     }
     // The automatic variant's LONE calls.  A call that finds NO launch of this context in flight — the host has fetched / synchronised
     // since the last one: every frame of the reference's window loop, accumulate() x 1 then fetch_image() (earth_viewer.py:241-243), or a
@@ -1242,7 +1254,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         }
         if (lone_small) pipeline = false;
     }
-    const bool v5k = (c->kernel_variant == 5 || lone_small) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
+    const bool v5k = (c->kernel_variant == 5 || lone_small || budget_v5) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
     const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     c->launch_one_batch = v3k && batches == 1 && pipes >= 2;
@@ -1258,7 +1270,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         if (cap < 1) cap = 1;
         if (c->tune_max_spp > 0 && cap > (unsigned long long)c->tune_max_spp) cap = (unsigned long long)c->tune_max_spp;
         if (v3k) {   // the stage queues hold 512 B per path
-            unsigned long long cap3 = (unsigned long long)c->v3_max_items / (nt * 64ull);
+            unsigned long long cap3 = (unsigned long long)(budget_fit && budget_fit < c->v3_max_items ? budget_fit : c->v3_max_items) / (nt * 64ull);
             if (cap3 < 1) cap3 = 1;
             if (cap > cap3) cap = cap3;
             // two pipes: a call is cut in (at least) two batches that run side by side
@@ -1281,6 +1293,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             if (nb >= 2 && call_items >= c->auto_min_items && cap > (unsigned long long)((spp + nb - 1) / nb)) cap = (unsigned long long)((spp + nb - 1) / nb);
         }
         if ((unsigned long long)max_spp > cap) max_spp = (int)cap;
+        if (max_spp < spp) { const int nl = (spp + max_spp - 1) / max_spp; max_spp = (spp + nl - 1) / nl; }      // launches of equal size: 64 spp under a cap of 15 is 5 x 13, not 4 x 15 + 4
         if (nt * 64ull * (unsigned long long)max_spp >= (1ull << 32) || nt * (unsigned long long)max_spp * (unsigned long long)max_spp >= (1ull << 40))
             return fail(DE_ERR_INVALID, "image too large for render_kernel_v2's 32-bit work-item index");
     }
