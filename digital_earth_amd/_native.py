@@ -87,6 +87,7 @@ SYMBOLS = {
     "de_get_memory_use": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "de_last_call_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "de_debug_v5_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
+    "de_debug_v6_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),
     "de_last_error": (ctypes.c_char_p, []),
     "de_abi_version": (ctypes.c_int, []),

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libdigitalearth_hip.so")
 SOURCES = ["de_api.hip"]   # single translation unit: includes render_kernel.hip and aux_kernels.hip
-DEPS = ["de_api.hip", "render_kernel.hip", "render_kernel_v2.hip", "render_kernel_v3.hip", "render_kernel_v5.hip", "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h",
+DEPS = ["de_api.hip", "render_kernel.hip", "render_kernel_v2.hip", "render_kernel_v3.hip", "render_kernel_v5.hip", "render_kernel_v6.hip", "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h",
         os.path.join("..", "..", "include", "digital_earth.h")]
 # -ffp-contract=off is part of the arithmetic contract (de_math.h): fused operations only where written.
 # -fno-slp-vectorize: the SLP vectoriser packs pairs of scalar f32 operations into v_pk_* instructions; on gfx950 the

@@ -16,6 +16,7 @@
 #include "render_kernel_v2.hip"
 #include "render_kernel_v3.hip"
 #include "render_kernel_v5.hip"
+#include "render_kernel_v6.hip"
 #include "aux_kernels.hip"
 
 namespace {
@@ -261,6 +262,16 @@ struct de_ctx {
         size_t cold_items = 0;
         uint32_t pool_chunks = 0, ring_cells = 0, n_shards = 0;
     } v5s[DE_MAX_SLOTS + 4];         // one per launch slot (kernel variant 5), then one per pipe (the pipeline's finisher, v3_finisher = 5)
+    // render_kernel_v6 (kernel variant 6): one persistent launch per call, one workgroup per CU, stage queues in LDS.  Per launch slot:
+    // the control words, one cold record per record slot of every workgroup, the launch's RenderArgs.
+    struct V6State {
+        wf::Cold* cold = nullptr;
+        uint32_t* ctl = nullptr;
+        RenderArgs* d_args = nullptr;
+        uint32_t* h_status = nullptr;     // pinned, device-visible: the kernel's abort code
+        uint32_t n_wg = 0;
+    } v6s[DE_MAX_SLOTS];
+    int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
     int v5_local = 1;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
@@ -510,6 +521,8 @@ int v3_reserve(de_ctx* c, int pipe, size_t n_items) {
     return DE_OK;
 }
 int v5_reserve(de_ctx* c, int idx, hipStream_t stream, size_t n_items);
+int v6_reserve(de_ctx* c, int idx, hipStream_t stream);
+hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx);
 hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx, const uint4* resume_rec = nullptr, const uint32_t* resume_count = nullptr,
                      const float* resume_cold = nullptr, uint32_t resume_capacity = 0, int wpc = 0);
 hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pipe) {
@@ -674,8 +687,52 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     }
     return hipGetLastError();
 }
+// render_kernel_v6: buffers of one launch slot (independent of the launch's size)
+int v6_reserve(de_ctx* c, int idx, hipStream_t stream) {
+    de_ctx::V6State& S = c->v6s[idx];
+    if (S.cold && S.n_wg == (uint32_t)c->n_cus) return DE_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (S.cold) hipFree(S.cold);
+    S.cold = nullptr; S.n_wg = (uint32_t)c->n_cus;
+    HIP_TRY(hipMalloc(&S.cold, (size_t)S.n_wg * DE_V6_P * sizeof(wf::Cold)));
+    if (!S.ctl) HIP_TRY(hipMalloc(&S.ctl, (size_t)bs::G_WORDS * DE_V6_CTL_STRIDE * sizeof(uint32_t)));
+    if (!S.d_args) HIP_TRY(hipMalloc(&S.d_args, sizeof(RenderArgs)));
+    if (!S.h_status) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.h_status), 64, hipHostMallocMapped));
+        S.h_status[0] = 0u;
+    }
+    return DE_OK;
+}
+hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx) {
+    de_ctx::V6State& S = c->v6s[idx];
+    const bool clamp = (c->p.flags & DE_FLAG_CLAMP_SAMPLER) != 0;
+    bs::Args A;
+    A.ra = S.d_args; A.cold = S.cold; A.ctl = S.ctl;
+    uint32_t* d_status = nullptr;
+    hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_status), S.h_status, 0);
+    if (e != hipSuccess) return e;
+    A.status = d_status;
+    A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
+    A.idle_limit = 1u << 22;
+    hipLaunchKernelGGL(v6_init_kernel, dim3(1), dim3(256), 0, stream, S.ctl, a, S.d_args);
+    // one workgroup per CU; a small launch: one per 1024 new paths (a workgroup's waves start 64 at a time)
+    const unsigned by_work = (unsigned)((A.n_items + 1023u) / 1024u);
+    dim3 grid(by_work < S.n_wg ? (by_work ? by_work : 1u) : S.n_wg), block(64 * DE_V6_WAVES);
+    if (c->v6_stats && !clamp) hipLaunchKernelGGL((v6_kernel<false, true>), grid, block, 0, stream, A, a.fc);
+    else if (clamp) hipLaunchKernelGGL((v6_kernel<true, false>), grid, block, 0, stream, A, a.fc);
+    else hipLaunchKernelGGL((v6_kernel<false, false>), grid, block, 0, stream, A, a.fc);
+    return hipGetLastError();
+}
 // after the host has synchronised: did a persistent launch leave on its abort word?
 int check_v5_status(de_ctx* c) {
+    for (int i = 0; i < DE_MAX_SLOTS; ++i) {
+        de_ctx::V6State& S = c->v6s[i];
+        if (S.h_status && S.h_status[0] != 0u) {
+            const uint32_t code = S.h_status[0];
+            S.h_status[0] = 0u;
+            return fail(DE_ERR_HIP, std::string("render_kernel_v6 left on its abort word (") + (code == bs::ERR_ENTRY_TIMEOUT ? "a ring entry was never stored" : "idle watchdog: work was lost") + "): the frame is invalid");
+        }
+    }
     for (int i = 0; i < DE_MAX_SLOTS + 4; ++i) {
         de_ctx::V5State& S = c->v5s[i];
         if (S.h_status && S.h_status[0] != 0u) {
@@ -698,6 +755,14 @@ hipError_t launch_render(de_ctx* c, const RenderArgs& a, hipStream_t stream, Pre
     if (!march && c->launch_variant == 5 && MODE == 0) {
         hipError_t e5 = launch_v5(c, a, stream, c->launch_slot);
         if (e5 != hipSuccess) return e5;
+        hipError_t pe = pre_acc();
+        if (pe != hipSuccess) return pe;
+        hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    if (!march && c->launch_variant == 6 && MODE == 0) {
+        hipError_t e6 = launch_v6(c, a, stream, c->launch_slot);
+        if (e6 != hipSuccess) return e6;
         hipError_t pe = pre_acc();
         if (pe != hipSuccess) return pe;
         hipLaunchKernelGGL(accumulate_kernel, grid, block, 0, stream, a);
@@ -826,8 +891,8 @@ namespace {
 //   DE_SLOTS / DE_BIG_SLOTS   launch slots (read next to their creation in de_create)
 void read_env_knobs(de_ctx* c) {
     c->trace = getenv("DE_AUTO_TRACE") != nullptr;
-    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '5') c->kernel_variant = kv[0] - '0'; }
-    c->launch_variant = (c->kernel_variant == 4 || c->kernel_variant == 5) ? 2 : c->kernel_variant;
+    if (const char* kv = getenv("DE_KERNEL")) { if (kv[0] >= '1' && kv[0] <= '6') c->kernel_variant = kv[0] - '0'; }
+    c->launch_variant = (c->kernel_variant >= 4) ? 2 : c->kernel_variant;
     {   // scheduler knobs of render_kernel_v2 (experiments): read once here, not per launch
         auto env_int = [](const char* name, int* v, int lo) { if (const char* e = getenv(name)) { int x = atoi(e); if (x >= lo) *v = x; } };
         env_int("DE_V2_THR", &c->tune_pend, 0); env_int("DE_V2_A", &c->tune_heavy, 0); env_int("DE_V2_B", &c->tune_b, 0);
@@ -851,7 +916,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_V3_WPC_CLOUD", &c->v3_wpc_class[2], 1); env_int("DE_V3_WPC_FLAT", &c->v3_wpc_class[3], 1);
         env_int("DE_V5_WPC", &c->v5_wpc, 1); env_int("DE_V5_SHARDS", &c->v5_shards, 1); env_int("DE_V5_POOL_LOG2", &c->v5_pool_log2, 10);
         env_int("DE_V5_CLAIM_K", &c->v5_claim_k, 1); env_int("DE_V5_AGE", &c->v5_age, 1); env_int("DE_V5_CLOSERS", &c->v5_closers_per_cu, 1);
-        env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
+        env_int("DE_V6_STATS", &c->v6_stats, 0); env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
         if (const char* e7 = getenv("DE_V5_MAX_ITEMS")) { long long x = atoll(e7); if (x >= 4096) c->v5_max_items = (size_t)x; }
         if (c->v5_shards > 32) c->v5_shards = 32;            // every ring has a cell per chunk of the pool (it cannot wrap): 1 MB x 7 per shard
         if (c->v5_pool_log2 > 19) c->v5_pool_log2 = 19;      // 2^19 chunks x 4 KB = 2 GB: the buffer descriptor addresses < 4 GB
@@ -963,6 +1028,10 @@ int de_destroy(de_ctx* c) {
         if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
         if (S.cold) hipFree(S.cold);
         if (S.d_args) hipFree(S.d_args);
+        if (S.h_status) hipHostFree(S.h_status);
+    }
+    for (auto& S : c->v6s) {
+        if (S.cold) hipFree(S.cold); if (S.ctl) hipFree(S.ctl); if (S.d_args) hipFree(S.d_args);
         if (S.h_status) hipHostFree(S.h_status);
     }
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
@@ -1255,7 +1324,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         if (lone_small) pipeline = false;
     }
     const bool v5k = (c->kernel_variant == 5 || lone_small || budget_v5) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
-    const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : c->kernel_variant);
+    const bool v6k = c->kernel_variant == 6 && v2 && !c->count;      // the per-CU stage scheduler (LDS queues)
+    const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : (c->kernel_variant == 6 ? (v6k ? 6 : 2) : c->kernel_variant));
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     c->launch_one_batch = v3k && batches == 1 && pipes >= 2;
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
@@ -1320,6 +1390,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         const int pipe = (v3k && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle; c->launch_slot = si;
         if (v5k) { int rc5 = v5_reserve(c, si, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
+        if (v6k) { int rc6 = v6_reserve(c, si, c->slot[si].stream); if (rc6) return rc6; }
         if (this_v3 && c->v3_finisher == 5 && c->launch_depths < 25) { int rc5 = v5_reserve(c, DE_MAX_SLOTS + pipe, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
         if (this_v3) {
             // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),
@@ -1561,8 +1632,8 @@ int de_last_accumulate_ms(de_ctx* c, float* ms) {
     return DE_OK;
 }
 int de_set_kernel_variant(de_ctx* c, int variant) {
-    if (!c || variant < 1 || variant > 5) return fail(DE_ERR_INVALID, "kernel variant must be 1 ... 5");
-    c->kernel_variant = variant; c->launch_variant = (variant == 4 || variant == 5) ? 2 : variant;
+    if (!c || variant < 1 || variant > 6) return fail(DE_ERR_INVALID, "kernel variant must be 1 ... 6");
+    c->kernel_variant = variant; c->launch_variant = variant >= 4 ? 2 : variant;
     return DE_OK;
 }
 int de_enable_counters(de_ctx* c, int enable) { if (!c) return fail(DE_ERR_INVALID, "null context"); c->count = enable != 0; return DE_OK; }
@@ -1701,6 +1772,21 @@ int de_debug_v5_stats(de_ctx* c, uint64_t* out, int n) {
         if (!S.ctl) continue;
         HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (int k = 0; k < n && k < ps::ST_N; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(ps::C_STAT0 + k) * DE_V5_CTL_STRIDE], 8); out[k] += v; }
+    }
+    return DE_OK;
+}
+
+/* the same for render_kernel_v6 (DE_V6_STATS=1): out[k] = word k of its ST_* list */
+int de_debug_v6_stats(de_ctx* c, uint64_t* out, int n) {
+    if (!c || !out || n < 0) return fail(DE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int k = 0; k < n; ++k) out[k] = 0;
+    std::vector<uint32_t> h((size_t)bs::G_WORDS * DE_V6_CTL_STRIDE);
+    for (auto& S : c->v6s) {
+        if (!S.ctl) continue;
+        HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < n && k < bs::ST_N; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_STAT0 + k) * DE_V6_CTL_STRIDE], 8); out[k] += v; }
     }
     return DE_OK;
 }

@@ -1,0 +1,435 @@
+// render_kernel_v6.hip — path_tracer (pathtracer.py:316-469) as ONE PERSISTENT KERNEL whose stage queues live in LDS: one stage
+// scheduler per workgroup (= per CU).
+//
+// Why.  render_kernel_v5 showed that the seven stage bodies of render_kernel_v3 can run inside one launch with coherent waves (lane
+// utilisation 0.67) — and that handing 64-byte records from wave to wave through HBM chunks and device-wide rings costs what the
+// coherence wins: every hop is a write-through, a ticket on a contended control word and a cold L2 read, and four single-class
+// waves per SIMD cannot cover those latencies.  Here a path never leaves the CU that started it.  A workgroup of sixteen waves owns
+// DE_V6_P record slots in its 160 KB of LDS; a path keeps ONE slot from its first ray to its contribution, and what travels between
+// the stages is the 16-bit slot number, through eight small rings (seven stages + the free slots) that also live in LDS.  A wave
+// asks the scheduler for the fullest ring, claims up to 64 slot numbers with one LDS compare-and-swap, runs the stage body — the
+// loop stages with persistent lanes that refill from the ring, as in v3 / v5 — writes the records back in place and appends the
+// slot numbers to the rings of the next stages.  No HBM queue traffic at all: the only global memory the scheduler touches is the
+// work counter (one fetch-add per 256 new paths), the paths' cold records (11 floats per SLOT: 32 MB for the whole GPU, L2 / MALL
+// resident) and the contribution of a path when it ends.
+//
+// Results are IDENTICAL to render_kernel_v2 / _v3 / _v5 / the CPU oracle: every path runs the same arithmetic in the same order on
+// its own RNG stream; only where and when changes.
+//
+// Visibility.  All waves of a workgroup share the CU's LDS and its L1: LDS operations of a wave execute in order, a record is
+// written (ds_write) before its slot number is (after a workgroup-scope release fence, which also drains the cold-record stores to
+// the L1/L2 both waves use); a ring entry is taken only after it has been seen non-empty (acquire).  A producer takes a ticket
+// (fetch-add on the ring's tail) and then stores the entries; the consumer that claimed a ticket early waits for the entry — a few
+// LDS round trips.  Every wait is bounded: a wave that waits too long raises the abort word and the host reports DE_ERR_HIP.
+#include "de_kernels.h"
+
+#ifndef DE_V6_YIELD
+#define DE_V6_YIELD 20             // a loop-stage wave whose ring is dry hands its records back when at most this many lanes are busy ...
+#endif
+#ifndef DE_V6_ELSEWHERE
+#define DE_V6_ELSEWHERE 48         // ... and another ring (or the free slots, while paths are left to start) holds at least this many entries
+#endif
+#ifndef DE_V6_RETRY
+#define DE_V6_RETRY 6              // trips between two looks at a dry ring
+#endif
+namespace bs {
+
+using wf::Path;
+using wf::NQ;
+using wf::Q_ST; using wf::Q_GAS; using wf::Q_CLOUD; using wf::Q_EVENT; using wf::Q_SURF; using wf::Q_SCFIN; using wf::Q_SURFFIN;
+
+enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
+#ifndef DE_V6_P
+#define DE_V6_P 1984u                      // record slots per workgroup: 4 x 16 B each = 124 KB of LDS
+#endif
+#define DE_V6_CAP 2048u                    // entries per ring (a power of two > DE_V6_P: an entry is never overwritten before it is taken)
+#define DE_V6_WAVES 16
+#define DE_V6_EMPTY 0xffffu
+#define DE_V6_CTL_STRIDE 32u
+// global control words (index x DE_V6_CTL_STRIDE dwords): 0 work counter, 8.. statistics (64-bit)
+enum { G_WORK = 0, G_STAT0 = 8, G_WORDS = 8 + 64 };
+// statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
+// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 24-26 trips of the loop stages, 27-29 busy lanes summed over those trips
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_TRIPS = 24, ST_LANETRIPS = 27, ST_N = 32 };
+enum { ERR_ENTRY_TIMEOUT = 1, ERR_IDLE_WATCHDOG = 3 };
+
+struct Args {
+    const RenderArgs* ra;       // the launch's RenderArgs in device memory (written by v6_init_kernel)
+    wf::Cold* cold;             // [workgroups x DE_V6_P] cold records, one per record slot
+    uint32_t* ctl;              // G_WORDS x DE_V6_CTL_STRIDE dwords
+    uint32_t* status;           // host-visible: [0] abort code (0 = clean)
+    uint32_t n_items;
+    uint32_t idle_limit;        // watchdog: scheduler rounds without work before a wave raises the abort word
+};
+template <int... T> struct Targets {};
+
+DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DE_DEV uint32_t ld_wg(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DE_DEV uint32_t add_wg(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DE_DEV uint32_t ld_e(const uint16_t* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DE_DEV void st_e(uint16_t* p, uint32_t v) { __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DE_DEV void release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+DE_DEV void acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// records in LDS, quad-major: the k-th 16 bytes of slot s at (k x DE_V6_P + s) x 16
+DE_DEV void load_rec(const uint4* rec, uint32_t s, Path& p) {
+    const uint4 a = rec[s], b = rec[DE_V6_P + s], c = rec[2u * DE_V6_P + s], d = rec[3u * DE_V6_P + s];
+    p.pid = a.x; p.meta = a.y; p.rng.s0 = a.z; p.rng.s1 = a.w; p.rng.draws = 0;
+    p.P = v3(wf::asf(b.x), wf::asf(b.y), wf::asf(b.z)); p.W = v3(wf::asf(b.w), wf::asf(c.x), wf::asf(c.y));
+    p.x[0] = wf::asf(c.z); p.x[1] = wf::asf(c.w); p.x[2] = wf::asf(d.x); p.x[3] = wf::asf(d.y); p.x[4] = wf::asf(d.z); p.x[5] = wf::asf(d.w);
+}
+DE_DEV void store_rec(uint4* rec, uint32_t s, const Path& p) {
+    rec[s] = make_uint4(p.pid, p.meta, p.rng.s0, p.rng.s1);
+    rec[DE_V6_P + s] = make_uint4(wf::asu(p.P.x), wf::asu(p.P.y), wf::asu(p.P.z), wf::asu(p.W.x));
+    rec[2u * DE_V6_P + s] = make_uint4(wf::asu(p.W.y), wf::asu(p.W.z), wf::asu(p.x[0]), wf::asu(p.x[1]));
+    rec[3u * DE_V6_P + s] = make_uint4(wf::asu(p.x[2]), wf::asu(p.x[3]), wf::asu(p.x[4]), wf::asu(p.x[5]));
+}
+
+// the cold record of the path in THIS lane's slot (the stage bodies index by path id; here the slot decides)
+struct ColdAt {
+    wf::Cold* c;
+    DE_DEV void get_thr_ls(uint32_t, float& thr, float& Ls) const { thr = c->thr; Ls = c->Ls; }
+    DE_DEV float get_ls(uint32_t) const { return c->Ls; }
+    DE_DEV void set_thr_ls(uint32_t, float thr, float Ls) const { c->thr = thr; c->Ls = Ls; }
+    DE_DEV vec3 get_dir(uint32_t) const { return v3(c->dx, c->dy, c->dz); }
+    DE_DEV void set_dir(uint32_t, vec3 D) const { c->dx = D.x; c->dy = D.y; c->dz = D.z; }
+    DE_DEV void set_surf(uint32_t, vec3 N, float alb, float ocean, float bathy) const { c->nx = N.x; c->ny = N.y; c->nz = N.z; c->alb = alb; c->ocean = ocean; c->bathy = bathy; }
+    DE_DEV void get_surf(uint32_t, vec3& N, float& alb, float& ocean, float& bathy) const { N = v3(c->nx, c->ny, c->nz); alb = c->alb; ocean = c->ocean; bathy = c->bathy; }
+};
+
+// Everything a wave carries between stages: wave-uniform.
+template <bool CLAMP, bool STATS>
+struct Wave {
+    const Args& A;
+    uint4* rec;                 // LDS: the workgroup's record slots
+    uint16_t* rings;            // LDS: NR rings of DE_V6_CAP slot numbers
+    uint32_t* cw;               // LDS: head[NR] at 0, tail[NR] at 8, abort at 16
+    const float* s_node_val;
+    wf::Cold* cold;             // the workgroup's cold records
+    unsigned long long* s_st;   // LDS: statistics
+    uint32_t n_work, w_lo, w_hi;
+    bool primary_left, aborted;
+    unsigned long long t_mark;
+
+    DE_DEV void stat(int k, unsigned long long v) { if (STATS && lane_id() == 0) __hip_atomic_fetch_add(s_st + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    template <int STAGE>
+    DE_DEV void mark() {
+        if (!STATS) return;
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        stat(STAGE >= 0 ? ST_CYC + STAGE : ST_SCHED, t - t_mark);
+        t_mark = t;
+    }
+    DE_DEV uint32_t* head(uint32_t q) const { return cw + q; }
+    DE_DEV uint32_t* tail(uint32_t q) const { return cw + 8u + q; }
+    DE_DEV void raise(uint32_t code) {
+        if (lane_id() == 0) {
+            __hip_atomic_store(cw + 16, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(A.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        aborted = true;
+    }
+    DE_DEV bool abort_seen() {      // the workgroup's own word: the workgroups share nothing but the work counter, the others finish their paths
+        if (!aborted && uni(ld_wg(cw + 16)) != 0u) aborted = true;
+        return aborted;
+    }
+
+    // claim between kmin and kmax entries of ring q: a compare-and-swap on its head, never past its tail
+    DE_DEV uint32_t claim(uint32_t q, uint32_t kmin, uint32_t kmax, uint32_t* first) {
+        uint32_t got = 0, hh = 0;
+        if (lane_id() == 0) {
+            uint32_t h = ld_wg(head(q));
+#pragma nounroll
+            for (int tries = 0; tries < 16; ++tries) {
+                const uint32_t t = ld_wg(tail(q));
+                const int avail = (int)(t - h);
+                if (avail < (int)kmin) break;
+                const uint32_t k = (uint32_t)avail < kmax ? (uint32_t)avail : kmax;
+                uint32_t expected = h;
+                if (__hip_atomic_compare_exchange_strong(head(q), &expected, h + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { got = k; hh = h; break; }
+                h = expected;
+            }
+        }
+        *first = uni(hh);
+        return uni(got);
+    }
+    // the slot number in entry idx of ring q (claimed by this wave): wait until its producer has stored it, leave the entry empty
+    DE_DEV uint32_t take(uint32_t q, uint32_t idx) {
+        uint16_t* e = rings + q * DE_V6_CAP + (idx & (DE_V6_CAP - 1u));
+        uint32_t v = DE_V6_EMPTY;
+#pragma nounroll
+        for (uint32_t spins = 0; spins < (1u << 20); ++spins) {
+            v = ld_e(e);
+            if (v != DE_V6_EMPTY) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (v != DE_V6_EMPTY) st_e(e, DE_V6_EMPTY);
+        return v;
+    }
+    // append the slot numbers of the lanes with pred to ring Q (their records are written and released)
+    template <int Q>
+    DE_DEV void push(uint32_t slot, bool pred) {
+        const unsigned long long mask = __ballot(pred);
+        if (mask == 0ull) return;
+        const uint32_t n = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+        uint32_t base = 0;
+        if (lane_id() == 0) base = add_wg(tail(Q), n);
+        base = uni(base);
+        if (pred) st_e(rings + Q * DE_V6_CAP + ((base + rank) & (DE_V6_CAP - 1u)), slot);
+    }
+
+    // ---- the scheduler: which stage this wave runs next — a queue id, Q_PRIMARY, or Q_EXIT
+    DE_DEV int schedule() {
+        uint32_t idle = 0;
+        for (;;) {
+            if (abort_seen()) return Q_EXIT;
+            int ready = 0;
+            const uint32_t l = (uint32_t)lane_id();
+            if (l < (uint32_t)NR) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
+            int best_q = -1, best = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = __builtin_amdgcn_readlane(ready, q);
+                if (r > best) { best = r; best_q = q; }
+            }
+            const int free_slots = __builtin_amdgcn_readlane(ready, Q_FREE);
+            // new paths as soon as a wave-load of slots is free: the population stays at the pool's size, the rings stay deep
+            if (primary_left && free_slots >= 64) return Q_PRIMARY;
+            if (best_q >= 0) { stat(ST_ENTRIES, 1); return best_q; }
+            if (!primary_left && free_slots == (int)DE_V6_P) return Q_EXIT;      // every slot is home and nothing is left to start
+            stat(ST_IDLE, 1);
+            if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
+            if (idle < 16u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+        }
+    }
+
+    // ---- a loop stage: persistent lanes.  A lane takes a slot, loads its record, runs the stage's loop on it one step per trip of the
+    // wave loop, keeps the finished record until the wave's next service; a service writes the finished records back, appends their
+    // slots to the next stages' rings and refills the idle lanes from this stage's ring.
+    template <int Q, int SERVICE, typename Stage, int... TARGETS>
+    DE_DEV void run_loop(Stage& st, Targets<TARGETS...>) {
+        Path p;
+        uint32_t slot = 0;
+        bool busy = false, fin = false;
+        int target = -1;
+        bool dry = false;
+        uint32_t trips = 0, retry_at = 0;
+        for (;;) {
+            const int nb = __popcll(__ballot(busy));
+            const bool may_refill = !dry || trips >= retry_at;
+            if (nb == 0 || (64 - nb >= SERVICE && (may_refill || __ballot(fin) != 0ull))) {
+                if (__ballot(fin) != 0ull) {
+                    if (fin) store_rec(rec, slot, p);
+                    release_wg();
+                    (push<TARGETS>(slot, fin && target == TARGETS), ...);
+                    fin = false;
+                }
+                if (may_refill || nb == 0) {
+                    dry = false;
+                    const unsigned long long m_need = __ballot(!busy);
+                    uint32_t first = 0;
+                    const uint32_t got = claim(Q, 1u, (uint32_t)__popcll(m_need), &first);
+                    if (got == 0u) {
+                        dry = true; retry_at = trips + (uint32_t)DE_V6_RETRY;
+                        // Nothing to refill from, a few long records left, and other work waits: hand the records back — the loop's
+                        // state goes to the spare words of their cold records — so that they fill the idle lanes of another wave of this
+                        // stage instead of running here at a fraction of the wave (cloud segments have a heavy tail)
+                        if (nb > 0 && nb <= DE_V6_YIELD && work_elsewhere(Q)) {
+                            if (busy) {
+                                st.suspend(cold + slot);
+                                p.meta |= 0x80000000u;
+                                store_rec(rec, slot, p);
+                            }
+                            release_wg();
+                            push<Q>(slot, busy);
+                            stat(ST_YIELD, 1); stat(ST_YIELDED, (unsigned long long)nb);
+                            busy = false;
+                            break;
+                        }
+                    } else {
+                        const uint32_t my = (uint32_t)__popcll(m_need & ((1ull << lane_id()) - 1ull));
+                        const bool mine = !busy && my < got;
+                        uint32_t s = 0;
+                        if (mine) s = take(Q, first + my);
+                        if (__ballot(mine && s == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); break; }
+                        acquire_wg();
+                        if (mine) {
+                            slot = s; load_rec(rec, slot, p);
+                            const bool resumed = (p.meta & 0x80000000u) != 0u;
+                            p.meta &= 0x7fffffffu;
+                            st.begin(p);
+                            if (resumed) st.restore(cold + slot);
+                            busy = true;
+                        }
+                        stat(ST_RECS + Q, got);
+                    }
+                }
+                if (__ballot(busy) == 0ull) { if (dry || aborted) break; else continue; }
+            }
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, (unsigned long long)__popcll(__ballot(busy))); }
+            if (busy) {
+                if (st.step(p)) { target = st.finish(p); busy = false; fin = true; }
+            }
+            trips++;
+        }
+    }
+    // is there a wave-load of work outside ring q (another stage's ring, or free slots for new paths)?
+    DE_DEV bool work_elsewhere(uint32_t q) {
+        int ready = 0;
+        const uint32_t l = (uint32_t)lane_id();
+        if (l < (uint32_t)NR && l != q) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
+        if (l == (uint32_t)Q_FREE && !primary_left) ready = 0;
+        return __ballot(ready >= DE_V6_ELSEWHERE) != 0ull;
+    }
+
+    // ---- a straight-line stage: up to 64 slots per pass, one record per lane, written back in place
+    template <int Q, typename Body, int... TARGETS>
+    DE_DEV void run_flat(Body body, Targets<TARGETS...>) {
+        for (;;) {
+            uint32_t first = 0;
+            const uint32_t n = claim(Q, 1u, 64u, &first);
+            if (n == 0u) break;
+            const bool active = (uint32_t)lane_id() < n;
+            uint32_t slot = 0;
+            if (active) slot = take(Q, first + (uint32_t)lane_id());
+            if (__ballot(active && slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); break; }
+            acquire_wg();
+            Path p;
+            int target = -2;
+            if (active) {
+                load_rec(rec, slot, p);
+                target = body(p, ColdAt{cold + slot});
+                if (target >= 0) store_rec(rec, slot, p);
+            }
+            stat(ST_RECS + Q, n);
+            release_wg();
+            (push<TARGETS>(slot, target == TARGETS), ...);
+            push<Q_FREE>(slot, target == -1);
+        }
+    }
+
+    // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
+    DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
+        if (w_lo >= w_hi) {          // 256 work items per device-wide atomic: four passes
+            uint32_t w = 0;
+            if (lane_id() == 0) w = __hip_atomic_fetch_add(A.ctl + G_WORK * DE_V6_CTL_STRIDE, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = uni(w);
+            if (w >= n_work) { primary_left = false; return; }
+            w_lo = w; w_hi = min(w + 256u, n_work);
+        }
+        const uint32_t n = min(64u, w_hi - w_lo);
+        uint32_t first = 0;
+        if (claim(Q_FREE, n, n, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return; }      // another wave was quicker: back to the scheduler
+        const uint32_t w = w_lo + (uint32_t)lane_id();
+        w_lo += n;
+        const bool active = (uint32_t)lane_id() < n;
+        uint32_t slot = 0;
+        if (active) slot = take(Q_FREE, first + (uint32_t)lane_id());
+        if (__ballot(active && slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return; }
+        acquire_wg();
+        const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+        Path p;
+        int target = -2;
+        if (active) {
+            wf::new_path(a, fc, s_node_val, w, p);
+            const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
+            target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
+            store_rec(rec, slot, p);
+        }
+        stat(ST_RECS + NQ, n);
+        release_wg();
+        push<Q_GAS>(slot, target == Q_GAS);
+        push<Q_CLOUD>(slot, target == Q_CLOUD);
+        push<Q_EVENT>(slot, target == Q_EVENT);
+    }
+};
+
+}  // namespace bs
+
+#ifndef DE_V6_SVC_ST
+#define DE_V6_SVC_ST 16
+#endif
+#ifndef DE_V6_SVC_GAS
+#define DE_V6_SVC_GAS 16
+#endif
+#ifndef DE_V6_SVC_CLOUD
+#define DE_V6_SVC_CLOUD 12
+#endif
+
+// zero the control words and put the launch's RenderArgs where the persistent kernel reads them
+__global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (uint32_t)bs::G_WORDS) { ctl[i * DE_V6_CTL_STRIDE] = 0u; ctl[i * DE_V6_CTL_STRIDE + 1u] = 0u; }
+    if (i == 0u) *dst = a;
+}
+
+template <bool CLAMP, bool STATS>
+__global__ void __launch_bounds__(64 * DE_V6_WAVES) v6_kernel(bs::Args A, const FrameConsts* fcp) {
+    using namespace bs;
+    __shared__ uint4 s_rec[4u * DE_V6_P];
+    __shared__ uint16_t s_rings[NR * DE_V6_CAP];
+    __shared__ uint32_t s_cw[32];
+    __shared__ float s_node_val[64];
+    __shared__ unsigned long long s_stats[STATS ? 64 : 1];
+    for (uint32_t i = threadIdx.x; i < NR * DE_V6_CAP; i += blockDim.x) {
+        const uint32_t q = i / DE_V6_CAP, k = i % DE_V6_CAP;
+        s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? k : DE_V6_EMPTY);
+    }
+    if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : 0u;
+    if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; if (STATS) s_stats[threadIdx.x] = 0ull; }
+    __syncthreads();
+    Wave<CLAMP, STATS> W{A, s_rec, s_rings, s_cw, s_node_val, A.cold + (size_t)blockIdx.x * DE_V6_P, s_stats};
+    W.n_work = A.n_items; W.w_lo = W.w_hi = 0u; W.primary_left = true; W.aborted = false;
+    W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+
+    for (;;) {
+        const int s = W.schedule();
+        W.template mark<-1>();
+        if (s == Q_EXIT) break;
+        const RenderArgs& a = *v5_opaque(A.ra);
+        const FrameConsts& fc = *v5_opaque(fcp);
+        switch (s) {
+        case Q_ST: {
+            StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+            W.template run_loop<Q_ST, DE_V6_SVC_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+            W.template mark<Q_ST>();
+        } break;
+        case Q_GAS: {
+            GasStage st{a.nodes, a.dens_table};
+            W.template run_loop<Q_GAS, DE_V6_SVC_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+            W.template mark<Q_GAS>();
+        } break;
+        case Q_CLOUD: {
+            CloudStage<CLAMP> st{a.clouds};
+            W.template run_loop<Q_CLOUD, DE_V6_SVC_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+            W.template mark<Q_CLOUD>();
+        } break;
+        case Q_EVENT:
+            W.template run_flat<Q_EVENT>([&](Path& p, const ColdAt& cold) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
+            W.template mark<Q_EVENT>();
+            break;
+        case Q_SURF:
+            W.template run_flat<Q_SURF>([&](Path& p, const ColdAt& cold) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SURF>();
+            break;
+        case Q_SCFIN:
+            W.template run_flat<Q_SCFIN>([&](Path& p, const ColdAt& cold) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SCFIN>();
+            break;
+        case Q_SURFFIN:
+            W.template run_flat<Q_SURFFIN>([&](Path& p, const ColdAt& cold) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
+            W.template mark<Q_SURFFIN>();
+            break;
+        default:
+            W.run_primary(a, fc);
+            W.template mark<7>();
+            break;
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)ST_N && s_stats[threadIdx.x])
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.ctl + (G_STAT0 + threadIdx.x) * DE_V6_CTL_STRIDE), s_stats[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}

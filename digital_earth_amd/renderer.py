@@ -396,7 +396,7 @@ class Renderer:
         v = [ctypes.c_int() for _ in range(4)]
         check(self._lib.de_last_call_info(self._h, *[ctypes.byref(x) for x in v]))
         variant, pipes, depths, launches = (int(x.value) for x in v)
-        name = {0: "ray marcher", 1: "per-lane loops", 2: "state machine", 5: "persistent stage scheduler",
+        name = {0: "ray marcher", 1: "per-lane loops", 2: "state machine", 5: "persistent stage scheduler", 6: "per-CU stage scheduler",
                 3: "pipeline x%d, %d rounds%s" % (pipes, depths, " + state machine" if depths < 25 else "")}.get(variant, "?")
         return dict(variant=variant, pipes=pipes, depths=depths, launches=launches, kernel=name)
 
@@ -404,6 +404,12 @@ class Renderer:
         """Statistics block of the persistent stage scheduler (kernel variant 5 with DE_V5_STATS=1); include/digital_earth.h."""
         out = (ctypes.c_uint64 * n)()
         check(self._lib.de_debug_v5_stats(self._h, out, n))
+        return [int(x) for x in out]
+
+    def v6_stats(self, n=32):
+        """Statistics block of the per-CU stage scheduler (kernel variant 6 with DE_V6_STATS=1); include/digital_earth.h."""
+        out = (ctypes.c_uint64 * n)()
+        check(self._lib.de_debug_v6_stats(self._h, out, n))
         return [int(x) for x in out]
 
     def counters(self):

@@ -250,6 +250,10 @@ int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
  * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler, [23] in next_input, [24] in pushes, [25] in loop-stage services, [26] in straight-line bodies, [27..30] of the scheduler's: free-chunk refill, age flush, queue snapshot, claim, [32..34] wave-trips of the three loop
  * stages, [35..37] their lane-trips, [38] times a loop stage found its queue dry.  Profiling aid. */
 int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
+/* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 32: [0..7] records taken per stage
+ * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
+ * slots, [19] wave-time in the scheduler, [24..26] wave-trips of the three loop stages, [27..29] their lane-trips.  Profiling aid. */
+int de_debug_v6_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 
 const char* de_last_error(void);

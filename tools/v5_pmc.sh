@@ -4,7 +4,7 @@ TAG=${1:-v5}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT; export TMPDIR=/tmp; export DE_BIG_SLOTS=1; cd /tmp
-RX="v5_kernel|render_kernel_v2"
+RX="v5_kernel|v6_kernel|render_kernel_v2"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-include-regex "$RX" --output-format csv -d $OUT/sq1 -o pmc -- python3 $REPO/tools/frame.py "$@" > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "$RX" --output-format csv -d $OUT/sq2 -o pmc -- python3 $REPO/tools/frame.py "$@" > $OUT/sq2.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "$RX" --output-format csv -d $OUT/l2 -o pmc -- python3 $REPO/tools/frame.py "$@" > $OUT/l2.log 2>&1
