@@ -23,15 +23,6 @@
 // LDS round trips.  Every wait is bounded: a wave that waits too long raises the abort word and the host reports DE_ERR_HIP.
 #include "de_kernels.h"
 
-#ifndef DE_V6_YIELD
-#define DE_V6_YIELD 20             // a loop-stage wave whose ring is dry hands its records back when at most this many lanes are busy ...
-#endif
-#ifndef DE_V6_ELSEWHERE
-#define DE_V6_ELSEWHERE 48         // ... and another ring (or the free slots, while paths are left to start) holds at least this many entries
-#endif
-#ifndef DE_V6_RETRY
-#define DE_V6_RETRY 6              // trips between two looks at a dry ring
-#endif
 namespace bs {
 
 using wf::Path;
@@ -39,11 +30,26 @@ using wf::NQ;
 using wf::Q_ST; using wf::Q_GAS; using wf::Q_CLOUD; using wf::Q_EVENT; using wf::Q_SURF; using wf::Q_SCFIN; using wf::Q_SURFFIN;
 
 enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
-#ifndef DE_V6_P
-#define DE_V6_P 1984u                      // record slots per workgroup: 4 x 16 B each = 124 KB of LDS
+// Geometry.  The stage functions are separate (non-inlined) device functions: each gets the registers ITS body needs (36 ... 78, as the
+// stage kernels of render_kernel_v3.hip) instead of the 128 + spills the register allocator gives the seven stages inlined into one
+// function, so the kernel fits 80 VGPRs = 6 waves per SIMD.  24 waves per CU = two workgroups of twelve waves, 80 KB of LDS each.
+// (One workgroup of sixteen waves with 1984 slots at 128 VGPRs: 138 ms per frame; twelve of those waves: 177 ms — the kernel is bound by
+// VALU issue and latency hiding, both of which are waves per SIMD.)
+#ifndef DE_V6_WAVES
+#define DE_V6_WAVES 12                     // waves per workgroup
 #endif
-#define DE_V6_CAP 2048u                    // entries per ring (a power of two > DE_V6_P: an entry is never overwritten before it is taken)
-#define DE_V6_WAVES 16
+#ifndef DE_V6_WG_PER_CU
+#define DE_V6_WG_PER_CU 2
+#endif
+#ifndef DE_V6_WPE
+#define DE_V6_WPE 6                        // waves per SIMD the kernel is compiled for (DE_V6_WAVES x DE_V6_WG_PER_CU / 4)
+#endif
+#ifndef DE_V6_P
+#define DE_V6_P 960u                       // record slots per workgroup: 4 x 16 B each = 60 KB of LDS
+#endif
+#ifndef DE_V6_CAP
+#define DE_V6_CAP 1024u                    // entries per ring (a power of two > DE_V6_P: an entry is never overwritten before it is taken)
+#endif
 #define DE_V6_EMPTY 0xffffu
 #define DE_V6_CTL_STRIDE 32u
 // global control words (index x DE_V6_CTL_STRIDE dwords): 0 work counter, 8.. statistics (64-bit)
@@ -60,8 +66,35 @@ struct Args {
     uint32_t* status;           // host-visible: [0] abort code (0 = clean)
     uint32_t n_items;
     uint32_t idle_limit;        // watchdog: scheduler rounds without work before a wave raises the abort word
+    // tuning (de_api.hip: DE_V6_* environment)
+    uint32_t svc[3];            // idle lanes at which a loop stage (sphere trace, gas, cloud) services: pushes finished records, refills
+    uint32_t yield_max;         // a loop-stage wave whose ring is dry hands its records back when at most this many lanes are busy ...
+    uint32_t elsewhere_min;     // ... and another ring (or the free slots, while paths are left to start) holds at least this many entries
+    uint32_t retry;             // trips between two looks at a dry ring
+    uint32_t enter_min;         // the scheduler prefers rings with at least this many entries (a loop stage entered with fewer runs part-filled)
 };
 template <int... T> struct Targets {};
+
+// what every stage function needs of the launch: written to LDS once per workgroup, read (wave-uniform) at each stage entry
+struct Cfg {
+    const RenderArgs* ra;
+    const FrameConsts* fc;
+    wf::Cold* cold;             // this workgroup's DE_V6_P cold records
+    uint32_t* ctl;
+    uint32_t* status;
+    uint32_t n_items, idle_limit;
+    uint32_t svc[3];
+    uint32_t yield_max, elsewhere_min, retry, enter_min;
+    uint32_t pad;
+};
+static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 128, "Cfg is copied dword by dword");
+
+__shared__ uint4 s_rec[4u * DE_V6_P];                // the record slots, quad-major
+__shared__ uint16_t s_rings[(NQ + 1) * DE_V6_CAP];   // NR rings of slot numbers
+__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16
+__shared__ float s_node_val[64];
+__shared__ unsigned long long s_stats[64];
+__shared__ uint32_t s_cfg[32];
 
 DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -101,16 +134,26 @@ struct ColdAt {
 // Everything a wave carries between stages: wave-uniform.
 template <bool CLAMP, bool STATS>
 struct Wave {
-    const Args& A;
+    Cfg A;                      // wave-uniform copy of the workgroup's configuration
     uint4* rec;                 // LDS: the workgroup's record slots
     uint16_t* rings;            // LDS: NR rings of DE_V6_CAP slot numbers
     uint32_t* cw;               // LDS: head[NR] at 0, tail[NR] at 8, abort at 16
-    const float* s_node_val;
     wf::Cold* cold;             // the workgroup's cold records
     unsigned long long* s_st;   // LDS: statistics
     uint32_t n_work, w_lo, w_hi;
     bool primary_left, aborted;
     unsigned long long t_mark;
+
+    // a stage function's view of the wave: the configuration from LDS (scalar registers after the broadcast), the wave's own flag
+    DE_DEV static Wave enter(bool primary_left) {
+        Wave W;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&W.A);
+#pragma unroll
+        for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) dst[k] = uni(s_cfg[k]);
+        W.rec = s_rec; W.rings = s_rings; W.cw = s_cw; W.cold = W.A.cold; W.s_st = s_stats;
+        W.n_work = W.A.n_items; W.w_lo = W.w_hi = 0u; W.primary_left = primary_left; W.aborted = false; W.t_mark = 0ull;
+        return W;
+    }
 
     DE_DEV void stat(int k, unsigned long long v) { if (STATS && lane_id() == 0) __hip_atomic_fetch_add(s_st + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     template <int STAGE>
@@ -192,6 +235,9 @@ struct Wave {
                 const int r = __builtin_amdgcn_readlane(ready, q);
                 if (r > best) { best = r; best_q = q; }
             }
+            // a shallow ring is left alone for a few rounds (its records fill the idle lanes of the waves already in that stage, or it
+            // deepens) unless nothing else is there
+            if (best_q >= 0 && best < (int)A.enter_min && idle < 4u) best_q = -1;
             const int free_slots = __builtin_amdgcn_readlane(ready, Q_FREE);
             // new paths as soon as a wave-load of slots is free: the population stays at the pool's size, the rings stay deep
             if (primary_left && free_slots >= 64) return Q_PRIMARY;
@@ -206,8 +252,9 @@ struct Wave {
     // ---- a loop stage: persistent lanes.  A lane takes a slot, loads its record, runs the stage's loop on it one step per trip of the
     // wave loop, keeps the finished record until the wave's next service; a service writes the finished records back, appends their
     // slots to the next stages' rings and refills the idle lanes from this stage's ring.
-    template <int Q, int SERVICE, typename Stage, int... TARGETS>
+    template <int Q, typename Stage, int... TARGETS>
     DE_DEV void run_loop(Stage& st, Targets<TARGETS...>) {
+        const int SERVICE = (int)A.svc[Q];
         Path p;
         uint32_t slot = 0;
         bool busy = false, fin = false;
@@ -230,11 +277,11 @@ struct Wave {
                     uint32_t first = 0;
                     const uint32_t got = claim(Q, 1u, (uint32_t)__popcll(m_need), &first);
                     if (got == 0u) {
-                        dry = true; retry_at = trips + (uint32_t)DE_V6_RETRY;
+                        dry = true; retry_at = trips + A.retry;
                         // Nothing to refill from, a few long records left, and other work waits: hand the records back — the loop's
                         // state goes to the spare words of their cold records — so that they fill the idle lanes of another wave of this
                         // stage instead of running here at a fraction of the wave (cloud segments have a heavy tail)
-                        if (nb > 0 && nb <= DE_V6_YIELD && work_elsewhere(Q)) {
+                        if (nb > 0 && nb <= (int)A.yield_max && work_elsewhere(Q)) {
                             if (busy) {
                                 st.suspend(cold + slot);
                                 p.meta |= 0x80000000u;
@@ -279,7 +326,7 @@ struct Wave {
         const uint32_t l = (uint32_t)lane_id();
         if (l < (uint32_t)NR && l != q) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
         if (l == (uint32_t)Q_FREE && !primary_left) ready = 0;
-        return __ballot(ready >= DE_V6_ELSEWHERE) != 0ull;
+        return __ballot(ready >= (int)A.elsewhere_min) != 0ull;
     }
 
     // ---- a straight-line stage: up to 64 slots per pass, one record per lane, written back in place
@@ -331,7 +378,7 @@ struct Wave {
         Path p;
         int target = -2;
         if (active) {
-            wf::new_path(a, fc, s_node_val, w, p);
+            wf::new_path(a, fc, bs::s_node_val, w, p);
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
             store_rec(rec, slot, p);
@@ -346,15 +393,6 @@ struct Wave {
 
 }  // namespace bs
 
-#ifndef DE_V6_SVC_ST
-#define DE_V6_SVC_ST 16
-#endif
-#ifndef DE_V6_SVC_GAS
-#define DE_V6_SVC_GAS 16
-#endif
-#ifndef DE_V6_SVC_CLOUD
-#define DE_V6_SVC_CLOUD 12
-#endif
 
 // zero the control words and put the launch's RenderArgs where the persistent kernel reads them
 __global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
@@ -363,68 +401,101 @@ __global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
     if (i == 0u) *dst = a;
 }
 
-template <bool CLAMP, bool STATS>
-__global__ void __launch_bounds__(64 * DE_V6_WAVES) v6_kernel(bs::Args A, const FrameConsts* fcp) {
+// ---- the stage functions: NOT inlined into the kernel — one register allocation per stage (see "Geometry").  A stage function builds
+// its view of the wave from LDS, runs the stage until its ring is dry (or it hands its records back) and returns to the scheduler.
+#define DE_V6_STAGE template <bool CLAMP, bool STATS> __device__ __attribute__((noinline)) void
+DE_V6_STAGE v6_stage_st(bool primary_left) {
     using namespace bs;
-    __shared__ uint4 s_rec[4u * DE_V6_P];
-    __shared__ uint16_t s_rings[NR * DE_V6_CAP];
-    __shared__ uint32_t s_cw[32];
-    __shared__ float s_node_val[64];
-    __shared__ unsigned long long s_stats[STATS ? 64 : 1];
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    const FrameConsts& fc = *W.A.fc;
+    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
+    StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+    W.template run_loop<Q_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
+}
+DE_V6_STAGE v6_stage_gas(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    GasStage st{a.nodes, a.dens_table};
+    W.template run_loop<Q_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+}
+DE_V6_STAGE v6_stage_cloud(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    CloudStage<CLAMP> st{a.clouds};
+    W.template run_loop<Q_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
+}
+DE_V6_STAGE v6_stage_event(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    const FrameConsts& fc = *W.A.fc;
+    W.template run_flat<Q_EVENT>([&](Path& p, const ColdAt& cold) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
+}
+DE_V6_STAGE v6_stage_surf(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    const FrameConsts& fc = *W.A.fc;
+    W.template run_flat<Q_SURF>([&](Path& p, const ColdAt& cold) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
+}
+DE_V6_STAGE v6_stage_scfin(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    const FrameConsts& fc = *W.A.fc;
+    W.template run_flat<Q_SCFIN>([&](Path& p, const ColdAt& cold) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
+}
+DE_V6_STAGE v6_stage_surffin(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    const RenderArgs& a = *W.A.ra;
+    W.template run_flat<Q_SURFFIN>([&](Path& p, const ColdAt& cold) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
+}
+
+template <bool CLAMP, bool STATS>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64 * DE_V6_WAVES, 64 * DE_V6_WAVES), amdgpu_waves_per_eu(DE_V6_WPE, DE_V6_WPE)))
+v6_kernel(bs::Args A, const FrameConsts* fcp) {
+    using namespace bs;
     for (uint32_t i = threadIdx.x; i < NR * DE_V6_CAP; i += blockDim.x) {
         const uint32_t q = i / DE_V6_CAP, k = i % DE_V6_CAP;
         s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? k : DE_V6_EMPTY);
     }
     if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : 0u;
-    if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; if (STATS) s_stats[threadIdx.x] = 0ull; }
+    if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; s_stats[threadIdx.x] = 0ull; }
+    if (threadIdx.x == 0u) {
+        Cfg c;
+        c.ra = A.ra; c.fc = fcp; c.cold = A.cold + (size_t)blockIdx.x * DE_V6_P; c.ctl = A.ctl; c.status = A.status;
+        c.n_items = A.n_items; c.idle_limit = A.idle_limit;
+        c.svc[0] = A.svc[0]; c.svc[1] = A.svc[1]; c.svc[2] = A.svc[2];
+        c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.pad = 0u;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+        for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];
+    }
     __syncthreads();
-    Wave<CLAMP, STATS> W{A, s_rec, s_rings, s_cw, s_node_val, A.cold + (size_t)blockIdx.x * DE_V6_P, s_stats};
-    W.n_work = A.n_items; W.w_lo = W.w_hi = 0u; W.primary_left = true; W.aborted = false;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
     W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
 
     for (;;) {
         const int s = W.schedule();
         W.template mark<-1>();
         if (s == Q_EXIT) break;
-        const RenderArgs& a = *v5_opaque(A.ra);
-        const FrameConsts& fc = *v5_opaque(fcp);
         switch (s) {
-        case Q_ST: {
-            StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
-            W.template run_loop<Q_ST, DE_V6_SVC_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
-            W.template mark<Q_ST>();
-        } break;
-        case Q_GAS: {
-            GasStage st{a.nodes, a.dens_table};
-            W.template run_loop<Q_GAS, DE_V6_SVC_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
-            W.template mark<Q_GAS>();
-        } break;
-        case Q_CLOUD: {
-            CloudStage<CLAMP> st{a.clouds};
-            W.template run_loop<Q_CLOUD, DE_V6_SVC_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
-            W.template mark<Q_CLOUD>();
-        } break;
-        case Q_EVENT:
-            W.template run_flat<Q_EVENT>([&](Path& p, const ColdAt& cold) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
-            W.template mark<Q_EVENT>();
-            break;
-        case Q_SURF:
-            W.template run_flat<Q_SURF>([&](Path& p, const ColdAt& cold) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
-            W.template mark<Q_SURF>();
-            break;
-        case Q_SCFIN:
-            W.template run_flat<Q_SCFIN>([&](Path& p, const ColdAt& cold) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
-            W.template mark<Q_SCFIN>();
-            break;
-        case Q_SURFFIN:
-            W.template run_flat<Q_SURFFIN>([&](Path& p, const ColdAt& cold) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
-            W.template mark<Q_SURFFIN>();
-            break;
-        default:
+        case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
+        case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;
+        case Q_CLOUD: v6_stage_cloud<CLAMP, STATS>(W.primary_left); W.template mark<Q_CLOUD>(); break;
+        case Q_EVENT: v6_stage_event<CLAMP, STATS>(W.primary_left); W.template mark<Q_EVENT>(); break;
+        case Q_SURF: v6_stage_surf<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURF>(); break;
+        case Q_SCFIN: v6_stage_scfin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SCFIN>(); break;
+        case Q_SURFFIN: v6_stage_surffin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURFFIN>(); break;
+        default: {
+            const RenderArgs& a = *v5_opaque(W.A.ra);
+            const FrameConsts& fc = *v5_opaque(W.A.fc);
             W.run_primary(a, fc);
             W.template mark<7>();
-            break;
+        } break;
         }
     }
     if (STATS) {
