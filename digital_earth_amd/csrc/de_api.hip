@@ -302,6 +302,8 @@ struct de_ctx {
                                                             // Up to 40 M paths it would still win on latency (a lone 1/8 share 34.2 against 43.7 ms, 1/4 share 56.0 / 65.1), but the
                                                             // first call of every back-to-back run is a lone one, and a persistent launch ahead of pipeline launches cost such runs
                                                             // 3-8 % (12 steps of the 1/4 share: 46.2 against 42.8 ms per step): not by default
+    int auto_v6 = 1;                 // 1: the automatic variant runs calls of at least auto_v6_min_items paths on the per-CU stage scheduler (env DE_AUTO_V6)
+    unsigned long long auto_v6_min_items = 1ull << 18;      // (env DE_AUTO_V6_MIN_ITEMS)
     int auto_budget_v5 = 1;          // 1: a call the memory budget keeps off the pipeline runs the persistent scheduler when that fits (env DE_AUTO_BUDGET_V5)
     int auto_lone_v5 = 1;            // 1: a small call that finds nothing of this context in flight runs the persistent scheduler (env DE_AUTO_LONE_V5)
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
@@ -911,7 +913,8 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_AUTO_DEPTHS", &c->auto_depths, 1); if (c->auto_depths > 25) c->auto_depths = 25;
         env_int("DE_AUTO_WPC", &c->auto_wpc, 1); env_int("DE_AUTO_PIPES", &c->auto_pipes, 0); if (c->auto_pipes > 4) c->auto_pipes = 4;
         if (const char* e6 = getenv("DE_V3_TEST_BUDGET")) { long long x = atoll(e6); if (x > 0) c->v3_test_budget = (size_t)x; }
-        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_BUDGET_V5", &c->auto_budget_v5, 0); env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0); env_int("DE_AUTO_FULL_BATCHES1", &c->auto_full_batches1, 0);
+        env_int("DE_AUTO_MID", &c->auto_mid_mode, 1); env_int("DE_AUTO_LONE_V5", &c->auto_lone_v5, 0); env_int("DE_AUTO_BUDGET_V5", &c->auto_budget_v5, 0); env_int("DE_AUTO_V6", &c->auto_v6, 0);
+        if (const char* e6 = getenv("DE_AUTO_V6_MIN_ITEMS")) { long long x = atoll(e6); if (x >= 64) c->auto_v6_min_items = (unsigned long long)x; } env_int("DE_AUTO_MID_BATCHES1", &c->auto_mid_batches1, 0); env_int("DE_AUTO_FULL_BATCHES1", &c->auto_full_batches1, 0);
         env_int("DE_AUTO_DEEP_NS", &c->auto_deep_ns_x100, 0); env_int("DE_AUTO_DEEP_DEPTHS", &c->auto_deep_depths, 1); env_int("DE_AUTO_DEEP_PIPES", &c->auto_deep_pipes, 1);
         if (c->auto_deep_depths > 25) c->auto_deep_depths = 25; if (c->auto_deep_pipes > 4) c->auto_deep_pipes = 4;
         if (const char* e5 = getenv("DE_AUTO_TWO_PIPE_ITEMS")) { long long x = atoll(e5); if (x >= 0) c->auto_two_pipe_items = (unsigned long long)x; }
@@ -1232,9 +1235,14 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
     bool pipeline = false, mid_whole = false;
     int pipes = 1, batches = c->v3_batches;
+    // The automatic variant: every call of at least 2^18 paths runs the per-CU stage scheduler (render_kernel_v6.hip) in one launch per
+    // 2^29 paths — it ends a frame sooner than the pipeline + state machine on every camera and call size measured (1920x1080x64 spp:
+    // 122 against 162 ms per frame; a 1/8 share of it 21 against 26; 1 spp + fetch_image 10 against 15) and needs no queue memory.
+    // Smaller calls (and counting launches) run the state machine.  DE_AUTO_V6=0 brings back the policy of rounds 3-4 below.
+    const bool auto_v6 = c->kernel_variant == 4 && c->auto_v6 && v2 && !c->count && call_items >= c->auto_v6_min_items;
     if (c->kernel_variant == 3 && v2 && !c->count) {
         pipeline = true; pipes = c->v3_pipes; c->launch_depths = c->v3_depths; c->launch_wpc = c->v3_wpc;
-    } else if (c->kernel_variant == 4 && v2 && !c->count && call_items >= c->auto_min_items && spp >= 2) {
+    } else if (c->kernel_variant == 4 && !auto_v6 && v2 && !c->count && call_items >= c->auto_min_items && spp >= 2) {
         // what earlier launches found (whichever of them have completed: nothing is waited for; results do not depend on it)
         for (int i = 0; i < 4; ++i) {
             de_ctx::V3Pipe& P = c->v3p[i];
@@ -1321,7 +1329,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     // state machine cannot be shorter than its longest path in ONE lane; the scheduler's paths hop between waves that are all busy).  Calls
     // issued while others are in flight overlap through the launch slots on the state machine (64 x 1 spp: 295 against 523 ms).
     bool lone_small = false;
-    if (c->kernel_variant == 4 && c->auto_lone_v5 && v2 && !c->count && call_items >= (1ull << 18) && call_items <= c->auto_lone_max_items) {
+    if (c->kernel_variant == 4 && !auto_v6 && c->auto_lone_v5 && v2 && !c->count && call_items >= (1ull << 18) && call_items <= c->auto_lone_max_items) {
         lone_small = !launches_in_flight(c);
         if (c->mem_budget) {      // its pool, rings and cold records must fit the budget (one slot): otherwise the state machine, which needs none
             const unsigned long long fixed = ((unsigned long long)DE_V5_CH * 64ull << c->v5_pool_log2) + ((unsigned long long)c->v5_shards * wf::NQ * 4ull << c->v5_pool_log2);
@@ -1330,8 +1338,8 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         if (lone_small) pipeline = false;
     }
     const bool v5k = (c->kernel_variant == 5 || lone_small || budget_v5) && v2 && !c->count;      // the persistent stage scheduler (counting launches use the state machine)
-    const bool v6k = c->kernel_variant == 6 && v2 && !c->count;      // the per-CU stage scheduler (LDS queues)
-    const int base_variant = c->kernel_variant == 4 ? (v5k ? 5 : 2) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : (c->kernel_variant == 6 ? (v6k ? 6 : 2) : c->kernel_variant));
+    const bool v6k = (c->kernel_variant == 6 || auto_v6) && v2 && !c->count;      // the per-CU stage scheduler (LDS queues)
+    const int base_variant = c->kernel_variant == 4 ? (v6k ? 6 : (v5k ? 5 : 2)) : (c->kernel_variant == 5 ? (v5k ? 5 : 2) : (c->kernel_variant == 6 ? (v6k ? 6 : 2) : c->kernel_variant));
     const bool v3k = pipeline && v2 && !c->count;      // the call's launches run the wavefront pipeline
     c->launch_one_batch = v3k && batches == 1 && pipes >= 2;
     // A launch of render_kernel_v2 handles n_tiles*64*spp work items: the item index must fit 32 bits, the tile index is
@@ -1503,6 +1511,7 @@ int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
         if (S.pool) n += (uint64_t)S.pool_chunks * DE_V5_CH * 64u + (uint64_t)S.n_shards * wf::NQ * S.ring_cells * 4u + (uint64_t)S.pool_chunks * 4u;
         n += (uint64_t)S.cold_items * 64u;
     }
+    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 31 MB per launch slot, whatever the call
     *queue_bytes = n;
     return DE_OK;
 }

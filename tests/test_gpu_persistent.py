@@ -116,20 +116,22 @@ def test_persistent_scheduler_overlapping_calls(Renderer):
     assert bits_equal_fraction(fa, fb) == 1.0 and bits_equal_fraction(fb, fc) == 1.0
 
 
-def test_lone_small_calls_of_the_default_run_the_persistent_scheduler(Renderer):
-    """The default variant (round 4): a small call that finds nothing of its context in flight — the reference's window loop, accumulate()
-    then fetch_image() (earth_viewer.py:241-243) — runs render_kernel_v5 (its latency is what the user sees: 14.8 against 20.4 ms per
-    1920x1080 frame); small calls issued while others are in flight overlap on the state machine.  Same bits either way."""
+def test_lone_small_calls_of_the_earlier_policy_run_the_persistent_scheduler(Renderer, monkeypatch):
+    """The automatic variant's policy before render_kernel_v6 (DE_AUTO_V6=0): a small call that finds nothing of its context in flight —
+    the reference's window loop, accumulate() then fetch_image() (earth_viewer.py:241-243) — runs render_kernel_v5 (14.8 against 20.4 ms
+    per 1920x1080 frame); small calls issued while others are in flight overlap on the state machine.  Same bits either way.  (What the
+    default does today: tests/test_gpu_block_scheduler.py.)"""
+    monkeypatch.setenv("DE_AUTO_V6", "0")
     kw = dict(seed=6, texture_source="synthetic", texture_size=(4096, 2048))
     W, H = 1024, 512                                              # 524 288 paths per sample: above the 2^18 floor, below the pipeline's 8 M
-    a = Renderer((W, H), (0, 1, 0), **kw)                          # default variant, the loop: every call is alone
+    a = Renderer((W, H), (0, 1, 0), **kw)                          # the loop: every call is alone
     kinds = []
     for _ in range(5):
         a.accumulate(1)
         kinds.append(a.last_call_info()["variant"])
         a.fetch_image()
     assert kinds == [5] * 5, kinds
-    b = Renderer((W, H), (0, 1, 0), **kw)                          # default variant, calls back to back: only the first is alone
+    b = Renderer((W, H), (0, 1, 0), **kw)                          # calls back to back: only the first is alone
     kinds = []
     for _ in range(5):
         b.accumulate(1)
