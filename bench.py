@@ -382,7 +382,9 @@ def main():
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
                    "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
-                   "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3, "waves_per_cu": wpc, "primed_frames": n_prime,
+                   "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3,
+                   "waves_per_cu": 24 if timed_info["variant"] == 6 else wpc,      # render_kernel_v6: two workgroups of 12 waves per CU (80 VGPRs); the wave budget knob belongs to the state machine
+                   "primed_frames": n_prime,
                    "kernel": timed_info["kernel"], "launches_per_call": timed_info["launches"],
                    "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
@@ -408,7 +410,8 @@ def main():
         # The bound that holds is VALU issue.  Instructions per launch = SQ_INSTS_VALU of the committed rocprofv3 --pmc pass
         # of this workload (profiles/); active lanes per instruction = its SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU).
         # Two ceilings are quoted: the guide's 2 cycles per wave64 f32 instruction per SIMD-32 at 2.4 GHz, and the rate
-        # measured on this chip at this kernel's occupancy (tools/micro/dep_latency.hip: 1.05 ns at 5 waves per SIMD).
+        # measured on this chip with independent instruction streams at 4-5 waves per SIMD (tools/micro/dep_latency.hip: 1.05 ns;
+        # render_kernel_v6 runs 6 waves per SIMD, where the measured ceiling is not lower).
         ach_ginst = valu_insts / (avg_kernel_ms * 1e-3) / 1e9
         peak_meas = 256 * 4 / 1.05
         peak_guide = 256 * 4 * 2.4 / 2.0

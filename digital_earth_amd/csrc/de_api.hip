@@ -718,7 +718,7 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     if (e != hipSuccess) return e;
     A.status = d_status;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
-    A.idle_limit = 1u << 22;
+    A.idle_limit = 1u << 24;      // ~7 s of idling
     for (int k = 0; k < 3; ++k) A.svc[k] = (uint32_t)c->v6_svc[k];
     A.yield_max = (uint32_t)c->v6_yield; A.elsewhere_min = (uint32_t)c->v6_elsewhere; A.retry = (uint32_t)c->v6_retry; A.enter_min = (uint32_t)c->v6_enter_min;
     hipLaunchKernelGGL(v6_init_kernel, dim3(1), dim3(256), 0, stream, S.ctl, a, S.d_args);

@@ -55,8 +55,8 @@ enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
 // global control words (index x DE_V6_CTL_STRIDE dwords): 0 work counter, 8.. statistics (64-bit)
 enum { G_WORK = 0, G_STAT0 = 8, G_WORDS = 8 + 64 };
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
-// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 24-26 trips of the loop stages, 27-29 busy lanes summed over those trips
-enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_TRIPS = 24, ST_LANETRIPS = 27, ST_N = 32 };
+// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
 enum { ERR_ENTRY_TIMEOUT = 1, ERR_IDLE_WATCHDOG = 3 };
 
 struct Args {
@@ -349,6 +349,7 @@ struct Wave {
                 if (target >= 0) store_rec(rec, slot, p);
             }
             stat(ST_RECS + Q, n);
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, n); }
             release_wg();
             (push<TARGETS>(slot, target == TARGETS), ...);
             push<Q_FREE>(slot, target == -1);

@@ -406,7 +406,7 @@ class Renderer:
         check(self._lib.de_debug_v5_stats(self._h, out, n))
         return [int(x) for x in out]
 
-    def v6_stats(self, n=32):
+    def v6_stats(self, n=48):
         """Statistics block of the per-CU stage scheduler (kernel variant 6 with DE_V6_STATS=1); include/digital_earth.h."""
         out = (ctypes.c_uint64 * n)()
         check(self._lib.de_debug_v6_stats(self._h, out, n))

@@ -25,8 +25,8 @@ extern "C" {
 
 /* 1: round 1.  2: round 2 (contract-2 arithmetic, de_share_textures / de_trim_textures / de_comm_* added, DE_FLAG_NO_FAST_DIVISION
  * retired) — shipped still reporting 1.  3: launch slots (de_flush), de_use_own_stream, de_set_stream(NULL) = the null stream,
- * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_debug_v5_stats,
- * kernel variant 5. */
+ * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_debug_v5_stats, de_debug_v6_stats,
+ * kernel variants 5 and 6. */
 #define DE_ABI_VERSION 4
 /* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
 #define DE_ARITHMETIC_CONTRACT 2
@@ -207,21 +207,21 @@ int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);
 /* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
- *   4 (default)  automatic: a large call runs its first three vertex rounds in the wavefront pipeline (variant 3's stage kernels,
- *                batches side by side) and the surviving paths finish in the state machine (variant 2).  Large = more than 96 M
- *                paths: always (two batches; views with long paths — GPU time per path of EARLIER calls, read without waiting —
- *                get five rounds and three batches).  8 M .. 96 M paths (a rank's share of a tile partition): the pipeline on four
- *                pipes.  Smaller calls run variant 2 alone, overlapping through the launch slots — except a call of 2^18 .. 2^23 paths that
- *                finds nothing of this context in flight (accumulate(1) then fetch_image(), frame after frame): variant 5, for its
- *                latency.  The choices depend on the call's size and on what is in flight, never on a timing; they move time, never bits
+ *   4 (default)  automatic: a call of at least 2^18 paths runs the per-CU stage scheduler (variant 6) in one launch per 2^29 paths; smaller
+ *                calls (and counting launches) run the state machine (variant 2), overlapping through the launch slots.  The choice
+ *                depends on the call's size only and moves time, never bits.  (Environment DE_AUTO_V6=0: the policy of rounds 3-4 — the
+ *                first vertex rounds of a large call in the wavefront pipeline, batches side by side, the surviving paths in the state
+ *                machine; mid-size calls on four pipes; lone small calls on variant 5.)
  *   2            wave-level state machine only (render_kernel_v2.hip)
  *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
  *   1            per-lane loops (render_kernel.hip)
  *   5            persistent stage scheduler: ONE launch whose waves pick the fullest of seven chunked HBM queues (render_kernel_v5.hip)
- * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..5 selects the variant at de_create. */
+ *   6            per-CU stage scheduler: ONE launch, two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
+ * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..6 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
 /* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
- * persistent scheduler's pools: a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
+ * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 31 MB per
+ * launch slot whatever the call and is not affected): a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
  * pixel that does not fit runs on the state machine).  0 (default) = automatic: what the device has free minus 8 GB, at most 2^27 paths
  * per batch.  Setting it releases what is held.  profiles/memory_budget.md: throughput against the budget.
  * de_get_memory_use: bytes currently held for these buffers. */
@@ -250,9 +250,10 @@ int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
  * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler, [23] in next_input, [24] in pushes, [25] in loop-stage services, [26] in straight-line bodies, [27..30] of the scheduler's: free-chunk refill, age flush, queue snapshot, claim, [32..34] wave-trips of the three loop
  * stages, [35..37] their lane-trips, [38] times a loop stage found its queue dry.  Profiling aid. */
 int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
-/* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 32: [0..7] records taken per stage
+/* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 48: [0..7] records taken per stage
  * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
- * slots, [19] wave-time in the scheduler, [24..26] wave-trips of the three loop stages, [27..29] their lane-trips.  Profiling aid. */
+ * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [32..38] wave-trips of the loop
+ * stages / passes of the straight-line stages, [40..46] the busy lanes summed over them.  Profiling aid. */
 int de_debug_v6_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 

@@ -3,7 +3,7 @@ here without tools/summarize_profile.py, so that a stale or hand-edited JSON can
 import csv, json, os, re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_")
+RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel")
 
 
 def _per_frame(path, counters):
@@ -13,8 +13,15 @@ def _per_frame(path, counters):
         if RENDER.search(r["Kernel_Name"]):
             d = disp.setdefault(r["Dispatch_Id"], {"k": r["Kernel_Name"]})
             d[r["Counter_Name"]] = float(r["Counter_Value"])
-    frames = sum(1 for d in disp.values() if "v3_primary" in d["k"]) / 2.0        # two batches per frame
-    use = [d for d in disp.values() if not re.search(r"render_kernel_v2<\w+, 1>", d["k"])]   # not the 2-spp counting launch
+    prim = sum(1 for d in disp.values() if "v3_primary" in d["k"])
+    if prim:                                                                       # the wavefront pipeline: two batches per frame
+        frames = prim / 2.0
+        use = [d for d in disp.values() if not re.search(r"render_kernel_v2<\w+, 1>", d["k"])]   # not the 2-spp counting launch
+    else:                                                                          # one persistent launch per frame: the 64-spp launches
+        key = counters[0]
+        mx = max(d.get(key, 0.0) for d in disp.values())
+        use = [d for d in disp.values() if d.get(key, 0.0) >= 0.5 * mx]
+        frames = float(len(use))
     return {c: sum(d.get(c, 0.0) for d in use) / frames for c in counters}
 
 

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md + profiles/hbm_traffic.json.
 
-A frame of the bench workload is one de_accumulate(64) call.  With kernel variant 2 that is one render_kernel_v2 launch; with the
-default variant 4 it is a sequence: two batches side by side, each = the wavefront pipeline's stage kernels for the first vertex rounds
-(v3_*) + render_kernel_v2 as finisher.  Counters are therefore summed over ALL render kernels of a run and divided by its number
-of frames; the frame duration is the busy span of the render kernels in the kernel trace."""
+A frame of the bench workload is one de_accumulate(64) call.  With the default variant 4 that is one v6_kernel launch (round 4; kernel
+variants 2 / 5: one render_kernel_v2 / v5_kernel launch); with the wavefront pipeline (variant 3, and variant 4 until round 4) it is a
+sequence: batches side by side, each = the pipeline's stage kernels for the first vertex rounds (v3_*) + render_kernel_v2 as finisher.
+Counters are therefore summed over ALL render kernels of a run and divided by its number of frames; the frame duration is the busy span
+of the render kernels in the kernel trace between two display_kernel launches."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_")
+RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel")
 
 
 def read_csvs(pattern):
@@ -34,7 +35,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
     n_acc = sum(1 for r in trace if "accumulate_kernel" in r["Kernel_Name"])
     batches = max(1, round(n_primary / n_display)) if (n_primary and n_display) else 1
     kernel_ms = None
-    if n_primary and n_display:
+    if n_display:
         # frames run back to back: a frame = the kernels between two display_kernel launches (the bench displays every frame)
         ev = sorted(trace, key=lambda r: int(r["Start_Timestamp"]))
         spans, start, end = [], None, None
@@ -48,16 +49,18 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
         kernel_ms = sorted(spans)[len(spans) // 2]        # the first frames of a run also allocate the pipeline's queues
         out.append("* frames in the trace: %d (one de_accumulate(64) call each, displayed after it); first render-kernel start to last render-kernel end, median: **%.2f ms** (min %.2f, max %.2f)"
                    % (len(spans), kernel_ms, min(spans), max(spans)))
-        out.append("* a frame = %d batches side by side, each: the wavefront pipeline's stage kernels for the first vertex rounds + render_kernel_v2 as finisher of the surviving paths" % batches)
+        if n_primary: out.append("* a frame = %d batches side by side, each: the wavefront pipeline's stage kernels for the first vertex rounds + render_kernel_v2 as finisher of the surviving paths" % batches)
+        else: out.append("* a frame = one launch of the persistent kernel (the per-CU stage scheduler, render_kernel_v6.hip, unless a kernel variant was forced)")
         rsum = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace if RENDER.search(r["Kernel_Name"])) / 1e6 / max(n_display, 1)
-        out.append("* sum of the render kernels' own durations per frame: %.1f ms (the batches overlap)" % rsum)
+        out.append("* sum of the render kernels' own durations per displayed frame: %.1f ms%s" % (rsum, " (the batches overlap)" if n_primary else " (includes the bench's parity and counting launches)"))
         out.append("")
     else:
         for r in stats:
-            if r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
+            if r["Name"].startswith("void v6_kernel<false, false>") or r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
                 kernel_ms = float(r["AverageNs"]) / 1e6
     # counters: sum over every render kernel of a pass, per frame of that pass
     pmc, frames_in_pass = defaultdict(float), {}
+    passes_with = defaultdict(int)                             # a counter collected in several passes (SQ_WAVE_CYCLES) is averaged, not summed
     per_kernel = defaultdict(lambda: defaultdict(float))      # short kernel name -> counter -> per frame; "ms:<pass>" = duration sum
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         if not os.path.isdir(d): continue
@@ -77,6 +80,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
             mx = max((v.get(key, 0.0) for v in vals), default=0.0)
             use = [v for v in vals if v.get(key, 0.0) >= 0.5 * mx]                                            # the 64-spp launches
             nf = len(use)
+        for k in {k for v in use for k in v if k not in ("k", "ms")}: passes_with[k] += 1
         for v in use:
             short = re.sub(r"^void ", "", v["k"]).split("(")[0]
             for k, x in v.items():
@@ -85,7 +89,10 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                     pmc[k] += x / max(nf, 1)
                     per_kernel[short][k] += x / max(nf, 1)
     out += ["## PMC counters, all render kernels, per frame", "", "| counter | per frame |", "|---|---|"]
-    means = dict(pmc)
+    means = {k: x / max(passes_with[k], 1) for k, x in pmc.items()}
+    for c in per_kernel.values():
+        for k in list(c):
+            if not k.startswith("ms:") and passes_with[k] > 1: c[k] /= passes_with[k]
     for k in sorted(means):
         out.append("| %s | %.6g |" % (k, means[k]))
     out.append("")
@@ -122,9 +129,9 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                            "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag, "kernel_ms": kernel_ms,
                            "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": lane,
                            "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), summed over every render kernel of a frame (one "
-                                   "de_accumulate(64) call: the pipeline's stage kernels and render_kernel_v2); read bytes = 2 x FETCH_SIZE (a request "
+                                   "de_accumulate(64) call: one v6_kernel launch under the default variant); read bytes = 2 x FETCH_SIZE (a request "
                                    "moves a 128-B line and is tallied as 64 B: profiles/r2_fetch_calibration). L2-miss traffic at the fabric: "
-                                   "Infinity-Cache hits are included; with the pipeline it contains the queue records and cold records by design"},
+                                   "Infinity-Cache hits are included"},
                           f, indent=1)
     os.makedirs("profiles", exist_ok=True)
     with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:

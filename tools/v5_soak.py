@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the persistent stage scheduler: N frames of each of several shapes, every frame compared bit for bit with the state machine's
 (the hand-over between workgroups is concurrency: a rare stale record or lost chunk shows up as a wrong pixel or as the abort word).
-  python tools/v5_soak.py [frames]"""
+  python tools/v5_soak.py [frames]        DE_SOAK_VARIANT=6: the per-CU stage scheduler (render_kernel_v6.hip) instead"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -19,7 +19,7 @@ for (W, H, spp, preset, heavy) in ((1920, 1080, 1, None, False), (640, 360, 7, "
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(8192, 4096), cloud_heavy=heavy, seed=3)
     r.share_textures_from(ref)
     if preset: load_config(preset).apply(r)
-    r.set_kernel_variant(5)
+    r.set_kernel_variant(int(os.environ.get("DE_SOAK_VARIANT", "5")))
     ref.accumulate(spp); want = ref.fetch_hdr().view(np.uint32)
     n_bad = 0
     for k in range(N):

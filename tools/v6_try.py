@@ -37,13 +37,13 @@ def print_stats(r, ms):
     if not any(st):
         return
     tot = sum(st[8:16]) + st[19]
-    print("  stage            records      wave-time share   lane utilisation of the loop")
+    print("  stage            records      wave-time share   busy lanes per trip (loop stages) / pass (straight-line stages)")
     for k, name in enumerate(STAGES):
-        lu = ("%.3f   %d trips, %.2f us per trip" % (st[27 + k] / 64.0 / max(st[24 + k], 1), st[24 + k], st[8 + k] * 0.01 / max(st[24 + k], 1))) if k < 3 else ""
+        lu = ("%.3f   %d trips, %.2f us per trip" % (st[40 + k] / 64.0 / max(st[32 + k], 1), st[32 + k], st[8 + k] * 0.01 / max(st[32 + k], 1))) if k < 7 else ""
         print("  %-14s %10d   %6.1f %%   %s" % (name, st[k], 100.0 * st[8 + k] / max(tot, 1), lu))
     print("  %-14s %10s   %6.1f %%   (idle rounds %d, stage entries %d, failed free-slot claims %d, yields %d handing back %d records)"
           % ("scheduler", "", 100.0 * st[19] / max(tot, 1), st[16], st[17], st[18], st[20], st[21]))
-    print("  wave-time total %.1f ms x waves (launch %.1f ms x 4096 waves = %.1f)" % (tot * 10e-6, ms, ms * 4096))
+    print("  wave-time total %.1f ms x waves (launch %.1f ms x 6144 waves = %.1f)" % (tot * 10e-6, ms, ms * 6144))
 
 
 ok = True
