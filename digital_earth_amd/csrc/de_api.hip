@@ -303,7 +303,7 @@ struct de_ctx {
                                                             // first call of every back-to-back run is a lone one, and a persistent launch ahead of pipeline launches cost such runs
                                                             // 3-8 % (12 steps of the 1/4 share: 46.2 against 42.8 ms per step): not by default
     int auto_v6 = 1;                 // 1: the automatic variant runs calls of at least auto_v6_min_items paths on the per-CU stage scheduler (env DE_AUTO_V6)
-    unsigned long long auto_v6_min_items = 1ull << 18;      // (env DE_AUTO_V6_MIN_ITEMS)
+    unsigned long long auto_v6_min_items = 1ull << 12;      // (env DE_AUTO_V6_MIN_ITEMS; 32 768 paths per call: 4.9 against 8.4 ms per frame of the window loop, 0.74 against 1.21 ms per call back to back — tools/small_calls.py)
     int auto_budget_v5 = 1;          // 1: a call the memory budget keeps off the pipeline runs the persistent scheduler when that fits (env DE_AUTO_BUDGET_V5)
     int auto_lone_v5 = 1;            // 1: a small call that finds nothing of this context in flight runs the persistent scheduler (env DE_AUTO_LONE_V5)
     unsigned long long auto_min_items = 1ull << 23, auto_two_pipe_items = 48ull << 20;
@@ -1235,7 +1235,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
     bool pipeline = false, mid_whole = false;
     int pipes = 1, batches = c->v3_batches;
-    // The automatic variant: every call of at least 2^18 paths runs the per-CU stage scheduler (render_kernel_v6.hip) in one launch per
+    // The automatic variant: every call of at least 4096 paths runs the per-CU stage scheduler (render_kernel_v6.hip) in one launch per
     // 2^29 paths — it ends a frame sooner than the pipeline + state machine on every camera and call size measured (1920x1080x64 spp:
     // 122 against 162 ms per frame; a 1/8 share of it 21 against 26; 1 spp + fetch_image 10 against 15) and needs no queue memory.
     // Smaller calls (and counting launches) run the state machine.  DE_AUTO_V6=0 brings back the policy of rounds 3-4 below.

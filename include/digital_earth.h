@@ -207,7 +207,7 @@ int de_last_accumulate_ms(de_ctx* ctx, float* ms);
 int de_get_counters(de_ctx* ctx, de_counters* out);
 int de_enable_counters(de_ctx* ctx, int enable);
 /* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
- *   4 (default)  automatic: a call of at least 2^18 paths runs the per-CU stage scheduler (variant 6) in one launch per 2^29 paths; smaller
+ *   4 (default)  automatic: a call of at least 4096 paths runs the per-CU stage scheduler (variant 6) in one launch per 2^29 paths; smaller
  *                calls (and counting launches) run the state machine (variant 2), overlapping through the launch slots.  The choice
  *                depends on the call's size only and moves time, never bits.  (Environment DE_AUTO_V6=0: the policy of rounds 3-4 — the
  *                first vertex rounds of a large call in the wavefront pipeline, batches side by side, the surviving paths in the state

@@ -64,9 +64,10 @@ def test_ranks_on_one_gpu_match_one_rank(tmp_path, world):
     assert [pr["rank"] for pr in j2["per_rank"]] == list(range(world))
     assert sum(pr["tiles_owned"] for pr in j2["per_rank"]) == (256 // 8) * (128 // 8)
     assert all(pr["render_ms"] > 0 and pr["reduce_ms"] >= 0 for pr in j2["per_rank"])
-    assert j2["config"]["waves_per_cu"] == 20 and j2["config"]["launch_slots"] == 3
+    assert j2["config"]["waves_per_cu"] == 24 and j2["config"]["launch_slots"] == 3      # render_kernel_v6: two workgroups of twelve waves per CU
+    assert all(pr["kernel"] == "per-CU stage scheduler" for pr in j2["per_rank"])
     assert j2["alt"]["serial_frames"] is True and j2["alt"]["value"] > 0
-    assert j1["config"]["waves_per_cu"] == 20 and "alt" not in j1
+    assert j1["config"]["waves_per_cu"] == 24 and "alt" not in j1
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """render_kernel_v6 — path_tracer as ONE persistent kernel whose stage queues live in LDS, one scheduler per workgroup
-(csrc/render_kernel_v6.hip; the automatic variant's choice for every call of at least 2^18 paths since round 4) — is the same
+(csrc/render_kernel_v6.hip; the automatic variant's choice for every call of at least 4096 paths since round 4) — is the same
 function as the wave-level state machine, the wavefront pipeline, the HBM-queue scheduler and the oracle, bit for bit: the stage
 bodies are shared with render_kernel_v3, every path runs the same arithmetic on its own RNG stream, only where and when changes.
 What is new — and what these tests lean on — is (i) the hand-over of 16-bit slot numbers between the waves of a workgroup through
@@ -124,9 +124,10 @@ def test_block_scheduler_overlapping_calls(Renderer):
 
 
 def test_the_default_variant_chooses_by_call_size(Renderer, monkeypatch):
-    """The automatic variant (round 4): calls of at least 2^18 paths run render_kernel_v6, in the reference's window loop (accumulate()
-    then fetch_image(), earth_viewer.py:241-243) as well as back to back; smaller calls run the state machine; DE_AUTO_V6=0 brings
-    back the earlier policy (lone small calls on render_kernel_v5).  Same bits every way."""
+    """The automatic variant (round 4): calls of at least 4096 paths run render_kernel_v6, in the reference's window loop (accumulate()
+    then fetch_image(), earth_viewer.py:241-243) as well as back to back (tools/small_calls.py: it ends a call sooner than the state
+    machine from 4096 paths up); smaller calls run the state machine; DE_AUTO_V6=0 brings back the earlier policy (lone small calls
+    on render_kernel_v5).  Same bits every way."""
     kw = dict(seed=6, texture_source="synthetic", texture_size=(4096, 2048))
     W, H = 1024, 512                                              # 524 288 paths per sample
     a = Renderer((W, H), (0, 1, 0), **kw)
@@ -137,8 +138,10 @@ def test_the_default_variant_chooses_by_call_size(Renderer, monkeypatch):
         a.accumulate(1); kinds.append(a.last_call_info()["variant"])
     assert kinds == [6] * 5, kinds
     assert a.memory_use() < (1 << 30)                              # 31 MB of cold records per launch slot, no queues
-    s = Renderer((256, 128), (0, 1, 0), **kw); s.accumulate(4)    # 131 072 paths: the state machine
+    s = Renderer((32, 32), (0, 1, 0), **kw); s.accumulate(2)      # 2048 paths: the state machine
     assert s.last_call_info()["variant"] == 2
+    m = Renderer((64, 64), (0, 1, 0), **kw); m.accumulate(1)      # 4096 paths: the scheduler
+    assert m.last_call_info()["variant"] == 6
     monkeypatch.setenv("DE_AUTO_V6", "0")
     b = Renderer((W, H), (0, 1, 0), **kw)
     kinds = []

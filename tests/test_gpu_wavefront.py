@@ -10,6 +10,13 @@ from helpers import bits_equal_fraction, make_oracle, load_preset
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _pipeline_policy(monkeypatch):
+    """This file is about the wavefront pipeline and the launch policy built around it (rounds 3-4): the automatic kernel variant with
+    DE_AUTO_V6=0.  (Without it the automatic variant runs render_kernel_v6 for every call of 4096 paths and more: tests/test_gpu_block_scheduler.py.)"""
+    monkeypatch.setenv("DE_AUTO_V6", "0")
+
+
 @pytest.fixture(scope="module")
 def Renderer():
     from digital_earth_amd.renderer import Renderer as R
