@@ -273,7 +273,7 @@ struct de_ctx {
     } v6s[DE_MAX_SLOTS];
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v6_svc[3] = {16, 24, 16};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)
-    int v6_yield = 56, v6_elsewhere = 48, v6_retry = 6, v6_enter_min = 0;      // render_kernel_v6.hip: bs::Args (env DE_V6_YIELD / _ELSEWHERE / _RETRY / _ENTER_MIN)
+    int v6_yield = 56, v6_elsewhere = 48, v6_retry = 6, v6_enter_min = 0, v6_flat_min = 0;      // render_kernel_v6.hip: bs::Args (env DE_V6_YIELD / _ELSEWHERE / _RETRY / _ENTER_MIN)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
     int v5_local = 1;                // 1: teams live inside an XCD when the shard count is a multiple of 8 (env DE_V5_LOCAL)
@@ -720,7 +720,7 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
     A.idle_limit = 1u << 24;      // ~7 s of idling
     for (int k = 0; k < 3; ++k) A.svc[k] = (uint32_t)c->v6_svc[k];
-    A.yield_max = (uint32_t)c->v6_yield; A.elsewhere_min = (uint32_t)c->v6_elsewhere; A.retry = (uint32_t)c->v6_retry; A.enter_min = (uint32_t)c->v6_enter_min;
+    A.yield_max = (uint32_t)c->v6_yield; A.elsewhere_min = (uint32_t)c->v6_elsewhere; A.retry = (uint32_t)c->v6_retry; A.enter_min = (uint32_t)c->v6_enter_min; A.flat_min = (uint32_t)c->v6_flat_min;
     hipLaunchKernelGGL(v6_init_kernel, dim3(1), dim3(256), 0, stream, S.ctl, a, S.d_args);
     // DE_V6_WG_PER_CU workgroups per CU; a small launch: one per wave-load of new paths per wave (a workgroup's waves start 64 at a time)
     const unsigned by_work = (unsigned)((A.n_items + 64u * DE_V6_WAVES - 1u) / (64u * DE_V6_WAVES));
@@ -925,7 +925,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_V5_WPC", &c->v5_wpc, 1); env_int("DE_V5_SHARDS", &c->v5_shards, 1); env_int("DE_V5_POOL_LOG2", &c->v5_pool_log2, 10);
         env_int("DE_V5_CLAIM_K", &c->v5_claim_k, 1); env_int("DE_V5_AGE", &c->v5_age, 1); env_int("DE_V5_CLOSERS", &c->v5_closers_per_cu, 1);
         env_int("DE_V6_STATS", &c->v6_stats, 0); env_int("DE_V6_SVC_ST", &c->v6_svc[0], 1); env_int("DE_V6_SVC_GAS", &c->v6_svc[1], 1); env_int("DE_V6_SVC_CLOUD", &c->v6_svc[2], 1);
-        env_int("DE_V6_YIELD", &c->v6_yield, 0); env_int("DE_V6_ELSEWHERE", &c->v6_elsewhere, 1); env_int("DE_V6_RETRY", &c->v6_retry, 1); env_int("DE_V6_ENTER_MIN", &c->v6_enter_min, 0); env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
+        env_int("DE_V6_YIELD", &c->v6_yield, 0); env_int("DE_V6_ELSEWHERE", &c->v6_elsewhere, 1); env_int("DE_V6_RETRY", &c->v6_retry, 1); env_int("DE_V6_ENTER_MIN", &c->v6_enter_min, 0); env_int("DE_V6_FLAT_MIN", &c->v6_flat_min, 0); env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
         if (const char* e7 = getenv("DE_V5_MAX_ITEMS")) { long long x = atoll(e7); if (x >= 4096) c->v5_max_items = (size_t)x; }
         if (c->v5_shards > 32) c->v5_shards = 32;            // every ring has a cell per chunk of the pool (it cannot wrap): 1 MB x 7 per shard
         if (c->v5_pool_log2 > 19) c->v5_pool_log2 = 19;      // 2^19 chunks x 4 KB = 2 GB: the buffer descriptor addresses < 4 GB
