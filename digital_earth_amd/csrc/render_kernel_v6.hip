@@ -72,6 +72,7 @@ struct Args {
     uint32_t elsewhere_min;     // ... and another ring (or the free slots, while paths are left to start) holds at least this many entries
     uint32_t retry;             // trips between two looks at a dry ring
     uint32_t enter_min;         // the scheduler prefers rings with at least this many entries (a loop stage entered with fewer runs part-filled)
+    uint32_t flat_min;          // a straight-line stage is entered with fewer entries than this only when the loop stages' rings are empty (0: off; measured flat)
 };
 template <int... T> struct Targets {};
 
@@ -85,7 +86,7 @@ struct Cfg {
     uint32_t n_items, idle_limit;
     uint32_t svc[3];
     uint32_t yield_max, elsewhere_min, retry, enter_min;
-    uint32_t pad;
+    uint32_t flat_min;
 };
 static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 128, "Cfg is copied dword by dword");
 
@@ -229,12 +230,15 @@ struct Wave {
             int ready = 0;
             const uint32_t l = (uint32_t)lane_id();
             if (l < (uint32_t)NR) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
-            int best_q = -1, best = 0;
+            int best_q = -1, best = 0, low_q = -1, low = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int r = __builtin_amdgcn_readlane(ready, q);
-                if (r > best) { best = r; best_q = q; }
+                const bool shallow_flat = q > Q_CLOUD && r < (int)A.flat_min;      // the straight-line stages wait for a fuller pass while the loop stages have work
+                if (!shallow_flat && r > best) { best = r; best_q = q; }
+                if (shallow_flat && r > low) { low = r; low_q = q; }
             }
+            if (best_q < 0) { best_q = low_q; best = low; }
             // a shallow ring is left alone for a few rounds (its records fill the idle lanes of the waves already in that stage, or it
             // deepens) unless nothing else is there
             if (best_q >= 0 && best < (int)A.enter_min && idle < 4u) best_q = -1;
@@ -471,7 +475,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         c.ra = A.ra; c.fc = fcp; c.cold = A.cold + (size_t)blockIdx.x * DE_V6_P; c.ctl = A.ctl; c.status = A.status;
         c.n_items = A.n_items; c.idle_limit = A.idle_limit;
         c.svc[0] = A.svc[0]; c.svc[1] = A.svc[1]; c.svc[2] = A.svc[2];
-        c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.pad = 0u;
+        c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.flat_min = A.flat_min;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];
     }
