@@ -1511,7 +1511,7 @@ int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
         if (S.pool) n += (uint64_t)S.pool_chunks * DE_V5_CH * 64u + (uint64_t)S.n_shards * wf::NQ * S.ring_cells * 4u + (uint64_t)S.pool_chunks * 4u;
         n += (uint64_t)S.cold_items * 64u;
     }
-    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 31 MB per launch slot, whatever the call
+    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 33 MB per launch slot, whatever the call
     *queue_bytes = n;
     return DE_OK;
 }
