@@ -55,8 +55,8 @@ enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
 // global control words (index x DE_V6_CTL_STRIDE dwords): 0 work counter, 8.. statistics (64-bit)
 enum { G_WORK = 0, G_STAT0 = 8, G_WORDS = 8 + 64 };
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
-// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
-enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
+// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_DRAIN = 22, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
 enum { ERR_ENTRY_TIMEOUT = 1, ERR_IDLE_WATCHDOG = 3 };
 
 struct Args {
@@ -143,7 +143,7 @@ struct Wave {
     unsigned long long* s_st;   // LDS: statistics
     uint32_t n_work, w_lo, w_hi;
     bool primary_left, aborted;
-    unsigned long long t_mark;
+    unsigned long long t_mark, t_drain;
 
     // a stage function's view of the wave: the configuration from LDS (scalar registers after the broadcast), the wave's own flag
     DE_DEV static Wave enter(bool primary_left) {
@@ -152,7 +152,7 @@ struct Wave {
 #pragma unroll
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) dst[k] = uni(s_cfg[k]);
         W.rec = s_rec; W.rings = s_rings; W.cw = s_cw; W.cold = W.A.cold; W.s_st = s_stats;
-        W.n_work = W.A.n_items; W.w_lo = W.w_hi = 0u; W.primary_left = primary_left; W.aborted = false; W.t_mark = 0ull;
+        W.n_work = W.A.n_items; W.w_lo = W.w_hi = 0u; W.primary_left = primary_left; W.aborted = false; W.t_mark = 0ull; W.t_drain = 0ull;
         return W;
     }
 
@@ -366,7 +366,7 @@ struct Wave {
             uint32_t w = 0;
             if (lane_id() == 0) w = __hip_atomic_fetch_add(A.ctl + G_WORK * DE_V6_CTL_STRIDE, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             w = uni(w);
-            if (w >= n_work) { primary_left = false; return; }
+            if (w >= n_work) { primary_left = false; if (STATS) t_drain = __builtin_amdgcn_s_memrealtime(); return; }
             w_lo = w; w_hi = min(w + 256u, n_work);
         }
         const uint32_t n = min(64u, w_hi - w_lo);
@@ -486,7 +486,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
     for (;;) {
         const int s = W.schedule();
         W.template mark<-1>();
-        if (s == Q_EXIT) break;
+        if (s == Q_EXIT) { if (STATS && W.t_drain) W.stat(ST_DRAIN, __builtin_amdgcn_s_memrealtime() - W.t_drain); break; }
         switch (s) {
         case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
         case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;

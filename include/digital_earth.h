@@ -252,7 +252,7 @@ int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
 /* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 48: [0..7] records taken per stage
  * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
- * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [32..38] wave-trips of the loop
+ * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [22] wave-time between the end of the work items and the wave's exit, [32..38] wave-trips of the loop
  * stages / passes of the straight-line stages, [40..46] the busy lanes summed over them.  Profiling aid. */
 int de_debug_v6_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);

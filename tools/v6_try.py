@@ -43,6 +43,7 @@ def print_stats(r, ms):
         print("  %-14s %10d   %6.1f %%   %s" % (name, st[k], 100.0 * st[8 + k] / max(tot, 1), lu))
     print("  %-14s %10s   %6.1f %%   (idle rounds %d, stage entries %d, failed free-slot claims %d, yields %d handing back %d records)"
           % ("scheduler", "", 100.0 * st[19] / max(tot, 1), st[16], st[17], st[18], st[20], st[21]))
+    print("  drain: %.2f ms per wave and launch between the end of the work items and the wave's exit (two launches in these statistics)" % (st[22] * 1e-5 / 6144 / 2))
     print("  wave-time total %.1f ms x waves (launch %.1f ms x 6144 waves = %.1f)" % (tot * 10e-6, ms, ms * 6144))
 
 
@@ -66,6 +67,8 @@ if "--time" in sys.argv:
     piped = arg("--pipelined", 0, int) or 0
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic"); r.copy_textures(); r.trim_textures()
     if preset: load_config(preset).apply(r)
+    world = arg("--world", 1, int) or 1
+    if world > 1: r.set_tile_partition(0, world)
     for variant in (ref_variant, 6):
         r.set_kernel_variant(variant)
         r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
