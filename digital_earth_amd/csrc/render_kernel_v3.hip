@@ -672,10 +672,11 @@ struct StStage {
     }
     DE_DEV bool step(wf::Path& p) { Tok k; return issue(p, k) || resolve(p, k); }
     DE_DEV int finish(wf::Path& p) { return wf::after_sphere_trace(p, t, max_ray_dist); }
-    // the loop's state between two steps, to the spare words of the path's cold record and back (render_kernel_v6.hip: a wave that is
-    // left with a few long records hands them back to the queue; begin() runs first on the resuming lane, then restore())
-    DE_DEV void suspend(wf::Cold* c) const { c->pad0 = t; c->pad1 = wf::asf((uint32_t)cnt); }
-    DE_DEV void restore(const wf::Cold* c) { t = c->pad0; cnt = (int)wf::asu(c->pad1); }
+    // the loop's state between two steps: t goes where begin() reads it (p.x[0]; nothing after the loop reads that word), the rest to spare
+    // words of the path's cold record (render_kernel_v6.hip: a wave that is left with a few long records hands them back to the queue;
+    // begin() runs first on the resuming lane, then restore()).  pad0 is not used here: render_kernel_v6 keeps the path's id there.
+    DE_DEV void suspend(wf::Path& p, wf::Cold* c) const { p.x[0] = t; c->pad1 = wf::asf((uint32_t)cnt); }
+    DE_DEV void restore(const wf::Cold* c) { cnt = (int)wf::asu(c->pad1); }
 };
 template <bool CLAMP>
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_st_kernel(wf::Args A, const FrameConsts* __restrict__ fcp) {
@@ -759,8 +760,8 @@ struct GasStage {
         return wf::enter_cloud(p, p.x[2], p.x[3], (kind == 0) ? t : trn, p.x[4]);
     }
     // as StStage's: the running point C is accumulated step by step, so it travels with t and trn (event / ev_id are set by the last step only)
-    DE_DEV void suspend(wf::Cold* c) const { c->pad0 = t; c->pad1 = trn; c->pad2 = C.x; c->pad3 = C.y; c->pad4 = C.z; }
-    DE_DEV void restore(const wf::Cold* c) { t = c->pad0; trn = c->pad1; C = v3(c->pad2, c->pad3, c->pad4); }
+    DE_DEV void suspend(wf::Path& p, wf::Cold* c) const { p.x[0] = t; c->pad1 = trn; c->pad2 = C.x; c->pad3 = C.y; c->pad4 = C.z; }
+    DE_DEV void restore(const wf::Cold* c) { trn = c->pad1; C = v3(c->pad2, c->pad3, c->pad4); }
 };
 __global__ void __launch_bounds__(DE_V3_BLOCK) v3_gas_kernel(wf::Args A) {
     using namespace wf;
@@ -840,8 +841,8 @@ struct CloudStage {
         p.x[0] = aux; p.x[1] = trn; p.x[2] = X;                              // SCFIN / SURFFIN: trg, trn, li
         return (kind == 1) ? wf::Q_SCFIN : wf::Q_SURFFIN;
     }
-    DE_DEV void suspend(wf::Cold* c) const { c->pad0 = t; c->pad1 = trn; c->pad2 = C.x; c->pad3 = C.y; c->pad4 = C.z; }
-    DE_DEV void restore(const wf::Cold* c) { t = c->pad0; trn = c->pad1; C = v3(c->pad2, c->pad3, c->pad4); }
+    DE_DEV void suspend(wf::Path& p, wf::Cold* c) const { p.x[0] = t; c->pad1 = trn; c->pad2 = C.x; c->pad3 = C.y; c->pad4 = C.z; }
+    DE_DEV void restore(const wf::Cold* c) { trn = c->pad1; C = v3(c->pad2, c->pad3, c->pad4); }
 };
 // ------------------------------------------------------------------------------------------------ TRACK: gases, then the cloud shell, in one lane
 // A ray's tracking through the gases is followed by its tracking through the cloud shell (pathtracer.py:186 -> :198, :227 -> :231) for 85 %

@@ -45,10 +45,10 @@ enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
 #define DE_V6_WPE 6                        // waves per SIMD the kernel is compiled for (DE_V6_WAVES x DE_V6_WG_PER_CU / 4)
 #endif
 #ifndef DE_V6_P
-#define DE_V6_P 1008u                      // record slots per workgroup: 4 x 16 B each = 63 KB — with rings and the rest exactly the 80 KB a workgroup can have (960: +1.2 % time; 768: +11 %)
+#define DE_V6_P 1120u                      // record slots per workgroup, 56 B each (61 KB): with the rings and the rest the 80 KB a workgroup can have (1008: +x % time; 960: +1.2 % more; 768: +11 %)
 #endif
 #ifndef DE_V6_CAP
-#define DE_V6_CAP 1024u                    // entries per ring (a power of two > DE_V6_P: an entry is never overwritten before it is taken)
+#define DE_V6_CAP 1128u                    // entries per ring (> DE_V6_P: an entry is never overwritten before it is taken); indices are taken modulo this
 #endif
 #define DE_V6_EMPTY 0xffffu
 #define DE_V6_CTL_STRIDE 32u
@@ -90,7 +90,8 @@ struct Cfg {
 };
 static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 128, "Cfg is copied dword by dword");
 
-__shared__ uint4 s_rec[4u * DE_V6_P];                // the record slots, quad-major
+__shared__ uint4 s_rec[3u * DE_V6_P];                // the record slots: three 16-byte parts, part-major ...
+__shared__ uint2 s_rec2[DE_V6_P];                    // ... and one of 8 bytes
 __shared__ uint16_t s_rings[(NQ + 1) * DE_V6_CAP];   // NR rings of slot numbers
 __shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16
 __shared__ float s_node_val[64];
@@ -106,18 +107,20 @@ DE_DEV void st_e(uint16_t* p, uint32_t v) { __hip_atomic_store(p, (uint16_t)v, _
 DE_DEV void release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 DE_DEV void acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
-// records in LDS, quad-major: the k-th 16 bytes of slot s at (k x DE_V6_P + s) x 16
+// records in LDS: 56 bytes — meta, the generator, P, W, x[0..4] (x[5] is never read; the path's id lives in its cold record: a stage
+// that can end a path reads that line anyway) — as three 16-byte parts and one of 8, part-major
 DE_DEV void load_rec(const uint4* rec, uint32_t s, Path& p) {
-    const uint4 a = rec[s], b = rec[DE_V6_P + s], c = rec[2u * DE_V6_P + s], d = rec[3u * DE_V6_P + s];
-    p.pid = a.x; p.meta = a.y; p.rng.s0 = a.z; p.rng.s1 = a.w; p.rng.draws = 0;
-    p.P = v3(wf::asf(b.x), wf::asf(b.y), wf::asf(b.z)); p.W = v3(wf::asf(b.w), wf::asf(c.x), wf::asf(c.y));
-    p.x[0] = wf::asf(c.z); p.x[1] = wf::asf(c.w); p.x[2] = wf::asf(d.x); p.x[3] = wf::asf(d.y); p.x[4] = wf::asf(d.z); p.x[5] = wf::asf(d.w);
+    const uint4 a = rec[s], b = rec[DE_V6_P + s], c = rec[2u * DE_V6_P + s];
+    const uint2 d = s_rec2[s];
+    p.pid = 0u; p.meta = a.x; p.rng.s0 = a.y; p.rng.s1 = a.z; p.rng.draws = 0;
+    p.P = v3(wf::asf(a.w), wf::asf(b.x), wf::asf(b.y)); p.W = v3(wf::asf(b.z), wf::asf(b.w), wf::asf(c.x));
+    p.x[0] = wf::asf(c.y); p.x[1] = wf::asf(c.z); p.x[2] = wf::asf(c.w); p.x[3] = wf::asf(d.x); p.x[4] = wf::asf(d.y); p.x[5] = 0.0f;
 }
 DE_DEV void store_rec(uint4* rec, uint32_t s, const Path& p) {
-    rec[s] = make_uint4(p.pid, p.meta, p.rng.s0, p.rng.s1);
-    rec[DE_V6_P + s] = make_uint4(wf::asu(p.P.x), wf::asu(p.P.y), wf::asu(p.P.z), wf::asu(p.W.x));
-    rec[2u * DE_V6_P + s] = make_uint4(wf::asu(p.W.y), wf::asu(p.W.z), wf::asu(p.x[0]), wf::asu(p.x[1]));
-    rec[3u * DE_V6_P + s] = make_uint4(wf::asu(p.x[2]), wf::asu(p.x[3]), wf::asu(p.x[4]), wf::asu(p.x[5]));
+    rec[s] = make_uint4(p.meta, p.rng.s0, p.rng.s1, wf::asu(p.P.x));
+    rec[DE_V6_P + s] = make_uint4(wf::asu(p.P.y), wf::asu(p.P.z), wf::asu(p.W.x), wf::asu(p.W.y));
+    rec[2u * DE_V6_P + s] = make_uint4(wf::asu(p.W.z), wf::asu(p.x[0]), wf::asu(p.x[1]), wf::asu(p.x[2]));
+    s_rec2[s] = make_uint2(wf::asu(p.x[3]), wf::asu(p.x[4]));
 }
 
 // the cold record of the path in THIS lane's slot (the stage bodies index by path id; here the slot decides)
@@ -199,7 +202,7 @@ struct Wave {
     }
     // the slot number in entry idx of ring q (claimed by this wave): wait until its producer has stored it, leave the entry empty
     DE_DEV uint32_t take(uint32_t q, uint32_t idx) {
-        uint16_t* e = rings + q * DE_V6_CAP + (idx & (DE_V6_CAP - 1u));
+        uint16_t* e = rings + q * DE_V6_CAP + idx % DE_V6_CAP;
         uint32_t v = DE_V6_EMPTY;
 #pragma nounroll
         for (uint32_t spins = 0; spins < (1u << 20); ++spins) {
@@ -219,7 +222,7 @@ struct Wave {
         uint32_t base = 0;
         if (lane_id() == 0) base = add_wg(tail(Q), n);
         base = uni(base);
-        if (pred) st_e(rings + Q * DE_V6_CAP + ((base + rank) & (DE_V6_CAP - 1u)), slot);
+        if (pred) st_e(rings + Q * DE_V6_CAP + (base + rank) % DE_V6_CAP, slot);
     }
 
     // ---- the scheduler: which stage this wave runs next — a queue id, Q_PRIMARY, or Q_EXIT
@@ -287,7 +290,7 @@ struct Wave {
                         // stage instead of running here at a fraction of the wave (cloud segments have a heavy tail)
                         if (nb > 0 && nb <= (int)A.yield_max && work_elsewhere(Q)) {
                             if (busy) {
-                                st.suspend(cold + slot);
+                                st.suspend(p, cold + slot);
                                 p.meta |= 0x80000000u;
                                 store_rec(rec, slot, p);
                             }
@@ -349,6 +352,7 @@ struct Wave {
             int target = -2;
             if (active) {
                 load_rec(rec, slot, p);
+                p.pid = wf::asu(cold[slot].pad0);
                 target = body(p, ColdAt{cold + slot});
                 if (target >= 0) store_rec(rec, slot, p);
             }
@@ -387,6 +391,7 @@ struct Wave {
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
             store_rec(rec, slot, p);
+            cold[slot].pad0 = wf::asf(p.pid);
         }
         stat(ST_RECS + NQ, n);
         release_wg();
