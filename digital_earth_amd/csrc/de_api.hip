@@ -1394,7 +1394,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         int n = (spp - done < max_spp) ? spp - done : max_spp;
         // small launches (the interactive 1-spp pattern: a 16 MB record buffer, 3.5 ms of work behind a 15 ms tail) use all the
         // slots; big ones only the first few — each slot keeps a record buffer of the largest launch it has seen, and more
-        // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 133 MB of records:
+        // than three big persistent kernels side by side only dilute each other (1/8 frame at 64 spp, 137 MB of records:
         // 30.9 ms per frame with 3 slots, 35.1 ms with 8)
         const size_t need_bytes = v2 ? (size_t)a.n_tiles * 64u * (size_t)n * sizeof(uint2) : 0;
         // pipeline launches cycle through the call's pipes (one launch slot each)
@@ -1511,7 +1511,7 @@ int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
         if (S.pool) n += (uint64_t)S.pool_chunks * DE_V5_CH * 64u + (uint64_t)S.n_shards * wf::NQ * S.ring_cells * 4u + (uint64_t)S.pool_chunks * 4u;
         n += (uint64_t)S.cold_items * 64u;
     }
-    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 33 MB per launch slot, whatever the call
+    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 37 MB per launch slot, whatever the call
     *queue_bytes = n;
     return DE_OK;
 }

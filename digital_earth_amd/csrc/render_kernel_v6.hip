@@ -45,7 +45,7 @@ enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
 #define DE_V6_WPE 6                        // waves per SIMD the kernel is compiled for (DE_V6_WAVES x DE_V6_WG_PER_CU / 4)
 #endif
 #ifndef DE_V6_P
-#define DE_V6_P 1120u                      // record slots per workgroup, 56 B each (61 KB): with the rings and the rest the 80 KB a workgroup can have (1008: +x % time; 960: +1.2 % more; 768: +11 %)
+#define DE_V6_P 1120u                      // record slots per workgroup, 56 B each (61 KB): with the rings and the rest the 80 KB a workgroup can have (1008 slots of 64 B: +5.6 % time; 960: +7 %; 768: +19 %)
 #endif
 #ifndef DE_V6_CAP
 #define DE_V6_CAP 1128u                    // entries per ring (> DE_V6_P: an entry is never overwritten before it is taken); indices are taken modulo this

@@ -220,7 +220,7 @@ int de_enable_counters(de_ctx* ctx, int enable);
  * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..6 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
 /* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
- * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 33 MB per
+ * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 37 MB per
  * launch slot whatever the call and is not affected): a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
  * pixel that does not fit runs on the state machine).  0 (default) = automatic: what the device has free minus 8 GB, at most 2^27 paths
  * per batch.  Setting it releases what is held.  profiles/memory_budget.md: throughput against the budget.

@@ -81,7 +81,7 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
 
 def test_memory_budget_cuts_the_batches_not_the_bits(Renderer, monkeypatch):
     """de_set_memory_budget on the wavefront pipeline — the automatic variant's choice for large calls until the per-CU
-    stage scheduler took over (which holds 33 MB per launch slot whatever the call: tests/test_gpu_block_scheduler.py); DE_AUTO_V6=0
+    stage scheduler took over (which holds 37 MB per launch slot whatever the call: tests/test_gpu_block_scheduler.py); DE_AUTO_V6=0
     selects that policy.  1920x1088 x 64 spp = 134 M paths in two batches on two pipes, 512 B per path and pipe plus
     each pipe's room for holes (1.9 GB): 72 GB.  With 60 GB the pipes get 30 GB each: the batches shrink (more launches), the memory
     held stays inside the budget, the frame is the state machine's bit for bit; with a budget that leaves a pipe room for less than a

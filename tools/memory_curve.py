@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput against the memory budget of the pipeline's queues (de_set_memory_budget): BASELINE cfg2 and cfg4, pipelined frames.
 
-  DE_AUTO_V6=0 python tools/memory_curve.py [--cfg4]        -> one line per budget (the pipeline policy; the default holds 33 MB whatever the budget) (GB; 0 = automatic): ms per frame, bytes held, launches per call
+  DE_AUTO_V6=0 python tools/memory_curve.py [--cfg4]        -> one line per budget (the pipeline policy; the default holds 37 MB whatever the budget) (GB; 0 = automatic): ms per frame, bytes held, launches per call
 """
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
