@@ -1,16 +1,16 @@
 // render_kernel_v6.hip — path_tracer (pathtracer.py:316-469) as ONE PERSISTENT KERNEL whose stage queues live in LDS: one stage
-// scheduler per workgroup (= per CU).
+// scheduler per workgroup (two workgroups of twelve waves per CU).
 //
 // Why.  render_kernel_v5 showed that the seven stage bodies of render_kernel_v3 can run inside one launch with coherent waves (lane
 // utilisation 0.67) — and that handing 64-byte records from wave to wave through HBM chunks and device-wide rings costs what the
 // coherence wins: every hop is a write-through, a ticket on a contended control word and a cold L2 read, and four single-class
-// waves per SIMD cannot cover those latencies.  Here a path never leaves the CU that started it.  A workgroup of sixteen waves owns
-// DE_V6_P record slots in its 160 KB of LDS; a path keeps ONE slot from its first ray to its contribution, and what travels between
+// waves per SIMD cannot cover those latencies.  Here a path never leaves the CU that started it.  A workgroup owns DE_V6_P record
+// slots in LDS (its half of the CU's 160 KB); a path keeps ONE slot from its first ray to its contribution, and what travels between
 // the stages is the 16-bit slot number, through eight small rings (seven stages + the free slots) that also live in LDS.  A wave
 // asks the scheduler for the fullest ring, claims up to 64 slot numbers with one LDS compare-and-swap, runs the stage body — the
 // loop stages with persistent lanes that refill from the ring, as in v3 / v5 — writes the records back in place and appends the
 // slot numbers to the rings of the next stages.  No HBM queue traffic at all: the only global memory the scheduler touches is the
-// work counter (one fetch-add per 256 new paths), the paths' cold records (11 floats per SLOT: 32 MB for the whole GPU, L2 / MALL
+// work counter (one fetch-add per 256 new paths), the paths' cold records (64 bytes per SLOT: 37 MB for the whole GPU, L2 / MALL
 // resident) and the contribution of a path when it ends.
 //
 // Results are IDENTICAL to render_kernel_v2 / _v3 / _v5 / the CPU oracle: every path runs the same arithmetic in the same order on
@@ -21,6 +21,12 @@
 // the L1/L2 both waves use); a ring entry is taken only after it has been seen non-empty (acquire).  A producer takes a ticket
 // (fetch-add on the ring's tail) and then stores the entries; the consumer that claimed a ticket early waits for the entry — a few
 // LDS round trips.  Every wait is bounded: a wave that waits too long raises the abort word and the host reports DE_ERR_HIP.
+//
+// What makes it fast (profiles/experiments/README.md): (1) YIELD — a loop-stage wave whose ring is dry and that is left
+// with few busy lanes suspends its records (the loop's state travels in the record and in spare words of the cold record, bit for bit) and
+// hands them back to its own ring, where they fill the idle lanes of another wave; (2) every stage is a separate, non-inlined device
+// function: 76-80 VGPRs each instead of 128 + spills for the seven inlined, so six waves per SIMD fit; (3) 56-byte records: the LDS holds
+// 1.46 record slots per lane at that occupancy, and slots per lane is what bounds the design.
 #include "de_kernels.h"
 
 namespace bs {
