@@ -279,7 +279,9 @@ struct Wave {
             const bool may_refill = !dry || trips >= retry_at;
             if (nb == 0 || (64 - nb >= SERVICE && (may_refill || __ballot(fin) != 0ull))) {
                 if (__ballot(fin) != 0ull) {
-                    if (fin) store_rec(rec, slot, p);
+                    // the stage's epilogue for all the lanes that finished since the last service at once (run where a lane finishes it
+                    // would execute for two or three lanes of 64 in most trips)
+                    if (fin) { target = st.finish(p); store_rec(rec, slot, p); }
                     release_wg();
                     (push<TARGETS>(slot, fin && target == TARGETS), ...);
                     fin = false;
@@ -328,7 +330,7 @@ struct Wave {
             }
             if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, (unsigned long long)__popcll(__ballot(busy))); }
             if (busy) {
-                if (st.step(p)) { target = st.finish(p); busy = false; fin = true; }
+                if (st.step(p)) { busy = false; fin = true; }
             }
             trips++;
         }
