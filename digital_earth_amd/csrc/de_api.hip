@@ -272,7 +272,7 @@ struct de_ctx {
         uint32_t n_wg = 0;
     } v6s[DE_MAX_SLOTS];
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
-    int v6_svc[3] = {16, 24, 16};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)
+    int v6_svc[3] = {24, 24, 20};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)
     int v6_yield = 56, v6_elsewhere = 48, v6_retry = 6, v6_enter_min = 0, v6_flat_min = 0;      // render_kernel_v6.hip: bs::Args (env DE_V6_YIELD / _ELSEWHERE / _RETRY / _ENTER_MIN)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
