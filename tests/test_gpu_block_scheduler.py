@@ -165,3 +165,29 @@ def test_block_scheduler_full_frame(Renderer):
         r.accumulate(16)
         out.append(r.fetch_hdr())
     assert bits_equal_fraction(out[0], out[1]) == 1.0 and out[1].max() > 0
+
+
+def test_default_variant_on_odd_shapes_call_patterns_and_partitions(Renderer):
+    """The automatic variant against the state machine on shapes that stress the work-item mapping (one tile row / column, 1936x1088,
+    a single 16x8 frame below the 4096-path threshold), on call patterns that mix both kernels in one accumulation, on 130 spp in one
+    call, and as the sum of the ranks of 3-, 5- and 7-way tile partitions: bit for bit.  (tools/edge_sizes.py prints the same.)"""
+    kw = dict(seed=31, texture_source="synthetic", texture_size=(2048, 1024))
+    for (W, H, calls) in ((16, 8, [1]), (80, 40, [3, 1]), (208, 104, [7]), (1008, 8, [2, 2, 2]), (16, 1000, [5]), (1936, 1088, [2]), (640, 360, [1] * 9), (320, 200, [130])):
+        frames = []
+        for variant in (2, 4):
+            r = Renderer((W, H), (0, 1, 0), **kw)
+            r.set_kernel_variant(variant)
+            for s in calls:
+                r.accumulate(s)
+            frames.append(r.fetch_hdr())
+        assert bits_equal_fraction(frames[0], frames[1]) == 1.0, (W, H, calls)
+        assert frames[1].max() > 0
+    for world in (3, 5, 7):
+        full = Renderer((256, 128), (0, 1, 0), **kw); full.set_kernel_variant(2); full.accumulate(6)
+        acc = np.zeros_like(full.fetch_hdr())
+        for rank in range(world):
+            r = Renderer((256, 128), (0, 1, 0), **kw)
+            r.set_tile_partition(rank, world); r.accumulate(6)
+            assert r.last_call_info()["variant"] == 6
+            acc += r.fetch_hdr()
+        assert bits_equal_fraction(acc, full.fetch_hdr()) == 1.0, world
