@@ -57,6 +57,7 @@ SYMBOLS = {
     "de_reset": (ctypes.c_int, [_P]),
     "de_accumulate": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]),
     "de_fetch_image": (ctypes.c_int, [_P, _P]),
+    "de_fetch_image_view": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]),
     "de_render_to_image": (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     "de_fetch_hdr": (ctypes.c_int, [_P, _P]),
     "de_upload_hdr": (ctypes.c_int, [_P, _P, ctypes.c_int]),

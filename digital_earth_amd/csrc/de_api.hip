@@ -1564,6 +1564,18 @@ int de_fetch_image(de_ctx* c, float* out) {
     return copy_out(c, out, c->d_image);
 }
 
+int de_fetch_image_view(de_ctx* c, const float** host_image) {
+    if (!host_image) return fail(DE_ERR_INVALID, "host_image is null");
+    int rc = de_render_to_image(c, nullptr);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
+    if (!c->h_stage && hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault) != hipSuccess) { c->h_stage = nullptr; (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no pinned host memory for the staging buffer"); }
+    HIP_TRY(hipMemcpyAsync(c->h_stage, c->d_image, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *host_image = c->h_stage;
+    return check_v5_status(c);
+}
+
 int de_fetch_hdr(de_ctx* c, float* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -351,10 +351,18 @@ class Renderer:
         check(self._lib.de_accumulate(self._h, int(spp), self.seed, self.tile_rank, self.tile_world))
         self.current_spp += int(spp)
 
-    def fetch_image(self):
-        """renderer.py:382-384 — display transform of the accumulation; (W, H, 3) float32 in [0, 1]."""
+    def fetch_image(self, copy=True):
+        """renderer.py:382-384 — display transform of the accumulation; (W, H, 3) float32 in [0, 1].  copy=False returns a read-only
+        view of the library's pinned staging buffer, valid until the next fetch_* call on this renderer (what a window loop needs: it
+        hands the image to the canvas before it renders again) — no 24.9 MB host copy, no fresh pages."""
         if not self._textures_copied:
             self.copy_textures()
+        if not copy:
+            ptr = ctypes.POINTER(ctypes.c_float)()
+            check(self._lib.de_fetch_image_view(self._h, ctypes.byref(ptr)))
+            view = np.ctypeslib.as_array(ptr, shape=(self.image_res[0], self.image_res[1], 3))
+            view.flags.writeable = False
+            return view
         out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
         check(self._lib.de_fetch_image(self._h, out.ctypes.data))
         return out

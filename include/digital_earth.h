@@ -25,7 +25,7 @@ extern "C" {
 
 /* 1: round 1.  2: round 2 (contract-2 arithmetic, de_share_textures / de_trim_textures / de_comm_* added, DE_FLAG_NO_FAST_DIVISION
  * retired) — shipped still reporting 1.  3: launch slots (de_flush), de_use_own_stream, de_set_stream(NULL) = the null stream,
- * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_debug_v5_stats, de_debug_v6_stats,
+ * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_fetch_image_view, de_debug_v5_stats, de_debug_v6_stats,
  * kernel variants 5 and 6. */
 #define DE_ABI_VERSION 4
 /* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
@@ -147,6 +147,11 @@ int de_accumulate(de_ctx* ctx, int spp, uint64_t seed, int tile_rank, int tile_w
 /* fetch_image (renderer.py:382-384, 346-365): runs _render_to_image with samples = current_spp and copies
  * the (W, H, 3) f32 image to `out` (index (u*H + v)*3 + c, like the reference field). */
 int de_fetch_image(de_ctx* ctx, float* out);
+/* The same without the last copy: *host_image points at the context's pinned staging buffer, which holds the image until the next
+ * de_fetch_* call on this context (the window loop hands it to the canvas before it renders again: earth_viewer.py:241-243, 316-317).
+ * Saves the 24.9 MB host-to-host copy and the page faults of a fresh destination: 1920x1080, accumulate(1) + fetch per frame
+ * 10.4 -> 9.7 ms (tools/one_spp.py; 9.1 ms of it is the lone launch itself: its longest paths, tools/loop_breakdown.py). */
+int de_fetch_image_view(de_ctx* ctx, const float** host_image);
 /* Same transform, result left on the device (pointer valid until the context is destroyed). */
 int de_render_to_image(de_ctx* ctx, const float** device_image);
 /* color_buffer as (W, H, 3) f32 — the raw HDR accumulation (renderer.py:25,330) */

@@ -191,3 +191,18 @@ def test_default_variant_on_odd_shapes_call_patterns_and_partitions(Renderer):
             assert r.last_call_info()["variant"] == 6
             acc += r.fetch_hdr()
         assert bits_equal_fraction(acc, full.fetch_hdr()) == 1.0, world
+
+
+def test_fetch_image_view_is_the_image(Renderer):
+    """fetch_image(copy=False) — de_fetch_image_view: the display image in the library's pinned staging buffer, without the last host copy —
+    holds the same floats as fetch_image(), is read-only, and follows the accumulation."""
+    r = Renderer((256, 128), (0, 1, 0), seed=8, texture_source="synthetic", texture_size=(2048, 1024))
+    r.accumulate(3)
+    a = r.fetch_image()
+    v = r.fetch_image(copy=False)
+    assert v.shape == a.shape == (256, 128, 3) and v.dtype == np.float32 and not v.flags.writeable
+    assert (np.asarray(v) == a).all() and a.max() > 0
+    r.accumulate(2)
+    b = r.fetch_image()
+    v2 = r.fetch_image(copy=False)
+    assert (np.asarray(v2) == b).all() and not (b == a).all()

@@ -46,6 +46,13 @@ for _ in range(30):
     r.accumulate(1); img = r.fetch_image()
 t1 = time.perf_counter()
 print("interactive loop, accumulate(1) + fetch_image per frame: %.2f ms (%s)" % ((t1 - t0) * 1e3 / 30, r.last_call_info()["kernel"]))
+for _ in range(3):
+    r.accumulate(1); r.fetch_image(copy=False)
+t0 = time.perf_counter()
+for _ in range(30):
+    r.accumulate(1); img = r.fetch_image(copy=False)
+t1 = time.perf_counter()
+print("the same with fetch_image(copy=False) (a view of the pinned staging buffer): %.2f ms" % ((t1 - t0) * 1e3 / 30))
 if "--check" in sys.argv:
     r.reset_framebuffer(); r.accumulate(16); a = r.fetch_hdr()
     r.reset_framebuffer()
