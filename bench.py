@@ -50,10 +50,14 @@ def parse():
     ap.add_argument("--tex-size", type=int, nargs=2, default=None, help="override the size of every synthetic map (tests)")
     ap.add_argument("--reduce", choices=("torch", "lib"), default=os.environ.get("DE_REDUCE", "torch"),
                     help="N > 1 collective: torch.distributed (default) or the library's own RCCL communicator (de_comm_init / de_reduce)")
+    ap.add_argument("--split", choices=("tiles", "samples"), default=os.environ.get("DE_SPLIT", "tiles"),
+                    help="N > 1 partition of the frame: 8x8 tiles dealt diagonally + sum-reduce (default, north_star), or sample indices dealt "
+                         "round robin + rank-ordered gather-sum (SURVEY §8e's alternative; with --simulate-world: rank 0's share of either)")
     ap.add_argument("--progressive", type=int, default=0, metavar="K",
                     help="progressive frames (BASELINE cfg5, SURVEY §8e): out-of-place reduce + display every K spp instead of once per frame")
     ap.add_argument("--waves-per-cu", type=int, default=0,
-                    help="resident render waves per CU (1..20, default 20 = 5 per SIMD)")
+                    help="render_kernel_v2 only (calls below 4096 paths, counting launches): resident waves per CU, 1..20.  The timed kernel, "
+                         "render_kernel_v6, always runs two workgroups of 12 waves per CU and ignores this")
     ap.add_argument("--sync-frames", action="store_true",
                     help="wait for every frame before submitting the next (profiling: frames do not overlap in the trace)")
     ap.add_argument("--serial-frames", action="store_true",
@@ -191,11 +195,14 @@ def main():
                 box = [uid]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            frames.append(parallel.LibraryComm(rk, rank, world, exchange))
+            frames.append(parallel.LibraryComm(rk, rank, world, exchange, split=args.split))
         else:
-            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index, priority=-1)))
+            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index, priority=-1), split=args.split))
         if args.simulate_world > 1 and world == 1:
-            rk.set_tile_partition(0, args.simulate_world)
+            if args.split == "samples":
+                rk.set_sample_partition(0, args.simulate_world)
+            else:
+                rk.set_tile_partition(0, args.simulate_world)
     r, frame = frames[0].r, frames[0]
     # Launch settings.  Frames overlap through the library's launch slots (3 for frame-sized launches).  With N > 1 the collective
     # of frame k is then enqueued while frame k+1 renders: the render kernel's persistent waves own every vector register of the
@@ -271,7 +278,7 @@ def main():
         np.save(args.dump_hdr, last.r.fetch_hdr())
 
     # untimed: one frame at a time (latency of a single frame), with the HIP-event duration of its render launch
-    per_launch, per_frame, per_reduce = [], [], []
+    per_launch, per_frame, per_reduce, per_drain = [], [], [], []
     for _ in range(max(1, min(args.steps, 3))):
         barrier()
         tf = time.perf_counter()
@@ -280,9 +287,14 @@ def main():
         per_frame.append(time.perf_counter() - tf)
         per_launch.append(r.last_accumulate_ms())
         per_reduce.append(frame.last_reduce_ms() if world > 1 else 0.0)
+        try:
+            per_drain.append(r.last_launch_phases())      # render_kernel_v6's own clock: (launch, drain) of this frame's launch
+        except Exception:
+            pass
     avg_kernel_ms = float(np.mean(per_launch))
     single_frame_ms = float(np.mean(per_frame)) * 1e3
     my_render_ms, my_reduce_ms = avg_kernel_ms, float(np.mean(per_reduce))
+    my_drain_ms = float(np.mean([d[1] for d in per_drain])) if per_drain else None
 
     # N > 1: the same K steps under the OTHER launch setting (serial <-> overlapping), untimed by the contract, reported as `alt`
     alt = None
@@ -306,7 +318,9 @@ def main():
         per_rank = [None] * world
         info = timed_info
         dist.all_gather_object(per_rank, {"rank": rank, "render_ms": my_render_ms, "reduce_ms": my_reduce_ms,
-                                          "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank]),
+                                          "drain_ms": my_drain_ms,      # of render_ms: from the first wave that found no work item left to the last wave's exit (a lone frame)
+                                          "tiles_owned": int(parallel.tiles_per_rank(W, H, world)[rank]) if args.split == "tiles" else (W // 8) * (H // 8),
+                                          "samples_per_pixel": spp if args.split == "tiles" else len(range(rank, spp, world)),
                                           "kernel": info["kernel"], "launches_per_call": info["launches"]})
         if args.check_spp > 0:
             # parity of the N-rank path on THIS hardware: the assembled frame must equal a 1-rank render bit for bit.
@@ -326,7 +340,9 @@ def main():
                     solo.close()
                     multi = {"spp": args.check_spp,
                              "bit_identical_fraction": float((assembled.view(np.uint32) == solo_hdr.view(np.uint32)).mean()),
-                             "nonzero_pixels": int((assembled != 0).any(axis=2).sum())}
+                             "rel_l2": float(np.sqrt(((assembled.astype(np.float64) - solo_hdr) ** 2).sum()) / max(np.sqrt((solo_hdr.astype(np.float64) ** 2).sum()), 1e-300)),
+                             "nonzero_pixels": int((assembled != 0).any(axis=2).sum()),
+                             "note": "tile partition: x + 0, bit-identical by construction; sample partition: rank-ordered partial sums, f32 re-association only (rel_l2 <= 1e-6)"}
                 barrier()
             except Exception as exc:          # noqa: BLE001 - reported, not swallowed
                 multi = {"spp": args.check_spp, "error": "%s: %s" % (type(exc).__name__, exc)}
@@ -339,9 +355,12 @@ def main():
     # B_sample = 8 B contribution record + 4 B per r8 tap + 16 B per colour tap (render_kernel_v2 writes one
     # 8-byte (radiance, wavelength node) record per sample, the HDR read-modify-write of 24 B per pixel per launch happens
     # in accumulate_kernel); samples per launch on this rank = its share of the frame.
-    my_samples = int(parallel.owned_pixel_mask(W, H, rank, world).sum()) * spp
-    if args.simulate_world > 1 and world == 1:
-        my_samples = int(parallel.owned_pixel_mask(W, H, 0, args.simulate_world).sum()) * spp
+    sim_world = args.simulate_world if (args.simulate_world > 1 and world == 1) else world
+    sim_rank = 0 if (args.simulate_world > 1 and world == 1) else rank
+    if args.split == "samples":
+        my_samples = W * H * len(range(sim_rank, spp, sim_world))
+    else:
+        my_samples = int(parallel.owned_pixel_mask(W, H, sim_rank, sim_world).sum()) * spp
     b_sample = 8.0 + 4.0 * n_r8 + 16.0 * n_rgb
     achieved_gbps = b_sample * my_samples / (avg_kernel_ms * 1e-3) / 1e9
     traffic = None
@@ -378,10 +397,12 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks_seen": ranks_seen, "devices_seen": devices_seen,
         "single_frame_ms": single_frame_ms, "single_frame_value": W * H * spp / (single_frame_ms * 1e-3) / 1e6,
+        "drain_ms": my_drain_ms,
         "config": {"workload": "%dx%d, %d spp, full spectral Rayleigh+Mie+O3+clouds, quality-%d synthetic maps%s, %s, "
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
-                   "parallelism": ("tile-partition x%d + %s reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1 else "single GPU",
+                   "parallelism": (("tile-partition x%d + %s reduce (%s)" if args.split == "tiles" else "sample-partition x%d + %s rank-ordered gather-sum (%s)") % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1
+                                  else ("single GPU" if args.simulate_world <= 1 else "single GPU rendering rank 0's share of a %s partition x%d (no collective)" % (args.split, args.simulate_world)),
                    "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3,
                    "waves_per_cu": 24 if timed_info["variant"] == 6 else wpc,      # render_kernel_v6: two workgroups of 12 waves per CU (80 VGPRs); the wave budget knob belongs to the state machine
                    "primed_frames": n_prime,
@@ -389,7 +410,12 @@ def main():
                    "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
         "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
+                     "frac": achieved_gbps / HBM_PEAK_GBPS,
+                     # `achieved` divides by the launch's own duration (HIP events around one frame rendered alone): the non-overlapped figure.
+                     # With frames back to back the next launch fills CUs as this one drains; the same bytes over ms_per_step:
+                     "frac_single_frame": achieved_gbps / HBM_PEAK_GBPS,
+                     "frac_overlapped_frames": (b_sample * my_samples / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": ("de_accumulate(%d): kernel variant %s — %s; "
                                 "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), timed_info["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
@@ -410,10 +436,10 @@ def main():
         # The bound that holds is VALU issue.  Instructions per launch = SQ_INSTS_VALU of the committed rocprofv3 --pmc pass
         # of this workload (profiles/); active lanes per instruction = its SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU).
         # Two ceilings are quoted: the guide's 2 cycles per wave64 f32 instruction per SIMD-32 at 2.4 GHz, and the rate
-        # measured on this chip with independent instruction streams at 4-5 waves per SIMD (tools/micro/dep_latency.hip: 1.05 ns;
-        # render_kernel_v6 runs 6 waves per SIMD, where the measured ceiling is not lower).
+        # measured on this chip with independent instruction streams at the kernel's occupancy (tools/micro/dep_latency.hip: one
+        # instruction per 1.00 ns per SIMD at the 6 waves per SIMD render_kernel_v6 runs — 1.05 ns at 5, 1.11 ns at 4).
         ach_ginst = valu_insts / (avg_kernel_ms * 1e-3) / 1e9
-        peak_meas = 256 * 4 / 1.05
+        peak_meas = 256 * 4 / 1.00
         peak_guide = 256 * 4 * 2.4 / 2.0
         lane_ops_per_sample = valu_insts * 64.0 * lane_util / my_samples
         out["valu"]["issue"] = {"achieved": ach_ginst, "unit": "1e9 wave64 VALU instructions/s",
@@ -454,13 +480,24 @@ def main():
         import threading
 
         printed = []
+        print_lock = threading.Lock()
+
+        def emit():
+            # the line goes out exactly once, whichever of the main thread and the watchdog gets here first
+            with print_lock:
+                if rank == 0 and not printed:
+                    print(json.dumps(out), flush=True)
+                    printed.append(True)
 
         def bail():
-            # this rank (or a peer it waits for) hangs in the leg, or in the barrier after it: the line goes out once, then the process ends
-            if rank == 0 and not printed:
-                out.setdefault("lib_reduce", {"error": "timed out after 120 s"})
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            # this rank (or a peer it waits for) hangs in the leg, or in the barrier after it: the measurement is kept — the line goes out with
+            # the failure in it — and the process ends NON-ZERO on every rank, so that a launcher sees the hang as a failure.
+            # No restart / re-exec: the process has touched the GPU.
+            out.setdefault("lib_reduce", {"error": "timed out after 120 s (rank %d)" % rank})
+            emit()
+            sys.stderr.write("bench.py: rank %d: the in-library RCCL leg (or the barrier after it) did not return within 120 s\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
         dog = threading.Timer(120.0, bail)
         dog.daemon = True
         dog.start()
@@ -489,9 +526,7 @@ def main():
             lf.close()
         except Exception as exc:          # noqa: BLE001 - reported, not swallowed
             out["lib_reduce"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if rank == 0:
-            print(json.dumps(out), flush=True)
-            printed.append(True)
+        emit()
         dist.barrier()                    # still under the watchdog: a peer that died in the leg must not hang this rank
         for f in frames:
             f.close()

@@ -73,6 +73,8 @@ SYMBOLS = {
     "de_comm_destroy": (ctypes.c_int, [_P]),
     "de_reduce": (ctypes.c_int, [_P, _P, ctypes.c_int]),
     "de_reduce_progressive": (ctypes.c_int, [_P, _P, ctypes.c_int]),
+    "de_set_sample_partition": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+    "de_reduce_ordered": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
     "de_last_reduce_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_set_display_source": (ctypes.c_int, [_P, _P]),
     "de_set_launch_slots": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
@@ -87,6 +89,7 @@ SYMBOLS = {
     "de_set_memory_budget": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "de_get_memory_use": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "de_last_call_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "de_last_launch_phases": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_debug_v5_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_v6_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),

@@ -34,5 +34,30 @@ def build(force=False, verbose=False):
     return OUT
 
 
+# Geometry variants of render_kernel_v6 for tests/test_gpu_round5.py::test_ring_protocol_on_small_pools: the same sources with -D flags
+# (tiny slot pools, a ring with no slack), loaded through DE_LIB_PATH by a child process; never the product library.
+TEST_VARIANTS = (("v6_p64", ["-DDE_V6_P=64u", "-DDE_V6_CAP=65u"]), ("v6_p128", ["-DDE_V6_P=128u", "-DDE_V6_CAP=129u"]), ("v6_cap_p1", ["-DDE_V6_CAP=1121u"]))
+
+
+def build_test_variants(force=False, verbose=False):
+    root = os.path.dirname(_HERE)
+    out_dir = os.path.join(root, "build", "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    newest = max(os.path.getmtime(os.path.join(CSRC, d)) for d in DEPS)
+    procs = []
+    for name, flags in TEST_VARIANTS:
+        out = os.path.join(out_dir, name + ".so")
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+            continue
+        cmd = [hipcc] + FLAGS + flags + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((name, subprocess.Popen(cmd, cwd=CSRC)))      # side by side: three ~45 s compiles on 8 cores
+    for name, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("building the test variant %s failed" % name)
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)

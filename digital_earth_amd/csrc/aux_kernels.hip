@@ -269,6 +269,24 @@ __global__ void __launch_bounds__(256) accumulate_kernel(RenderArgs a) {
     px[0] = acc_r; px[1] = acc_g; px[2] = acc_b;
 }
 
+// Root of a SAMPLE partition's collective (de_reduce_ordered): the ranks' partial sums added in rank order — ((p0 + p1) + p2) + ... — whatever
+// the interconnect did: parts[r] is the gathered buffer of rank r (the root's own accumulation buffer for r = root).  Streaming, float4.
+struct OrderedSumArgs { const float* part[16]; float* out; int n_parts; size_t n4, n; };
+__global__ void __launch_bounds__(256) ordered_sum_kernel(OrderedSumArgs a) {
+    typedef float de_f4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += stride) {
+        de_f4 acc = reinterpret_cast<const de_f4*>(a.part[0])[i];
+        for (int r = 1; r < a.n_parts; ++r) acc += reinterpret_cast<const de_f4*>(a.part[r])[i];
+        reinterpret_cast<de_f4*>(a.out)[i] = acc;
+    }
+    for (size_t i = a.n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        float acc = a.part[0][i];
+        for (int r = 1; r < a.n_parts; ++r) acc += a.part[r][i];
+        a.out[i] = acc;
+    }
+}
+
 // (W, H, 3) view of the [H][W][3] accumulation buffer: 32 x 32 tiles through LDS, contiguous on both sides
 __global__ void __launch_bounds__(256) hdr_transpose_kernel(const float* hdr, float* out, int W, int H) {
     __shared__ float tile[32][32 * 3 + 1];

@@ -200,7 +200,10 @@ struct de_ctx {
     bool count = false;
     de_counters counters;
     int current_spp = 0;
+    int sample_rank = 0, sample_world = 1;   // de_set_sample_partition: of the frame's sample indices this context renders those = rank (mod world)
     float* d_assembled = nullptr;   // root's receive buffer of de_reduce_progressive ([H][W][3])
+    float* d_gather = nullptr;      // root of de_reduce_ordered: the other ranks' buffers, [world][H][W][3]
+    int gather_world = 0;
     const float* display_src = nullptr;   // what the display transform / de_fetch_hdr read instead of d_hdr (de_set_display_source)
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;   // around the last collective
     bool reduce_timing_valid = false;
@@ -273,6 +276,7 @@ struct de_ctx {
     } v6s[DE_MAX_SLOTS];
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v6_svc[3] = {24, 24, 20};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)
+    int v6_svc_area[3] = {0, 0, 0};  // > 0: idle lane-trips since its last service at which a loop stage services (env DE_V6_AREA_ST / _GAS / _CLOUD)
     int v6_yield = 56, v6_elsewhere = 48, v6_retry = 6, v6_enter_min = 0, v6_flat_min = 0;      // render_kernel_v6.hip: bs::Args (env DE_V6_YIELD / _ELSEWHERE / _RETRY / _ENTER_MIN)
     int v5_wpc = 16;                 // waves per CU of the persistent grid (env DE_V5_WPC)
     int v5_shards = 32;              // queue sets (8 = one per XCD; env DE_V5_SHARDS)
@@ -312,6 +316,8 @@ struct de_ctx {
     // rounds on auto_deep_pipes pipes (env DE_AUTO_DEEP_NS in 1/100 ns per path / DE_AUTO_DEEP_DEPTHS / DE_AUTO_DEEP_PIPES)
     int auto_deep_ns_x100 = 200, auto_deep_depths = 5, auto_deep_pipes = 3;
     int last_v3_slot[4] = {-1, -1, -1, -1};  // a pipe's launches follow each other
+    bool frame_invalid = false;  // a persistent launch left on its abort word since the last de_reset: every fetch / reduce / synchronize reports it until then
+    std::string invalid_msg;
     de_ctx* lender = nullptr;    // the context whose maps and LUTs this one reads (de_share_textures)
     int loans = 0;               // contexts currently reading THIS context's maps: while > 0 they may not be freed or repacked
 };
@@ -341,13 +347,18 @@ bool launches_in_flight(de_ctx* c) {
 // context-stream work that the next launches must be ordered after: what a render kernel reads / the HDR buffer
 void touched_render_inputs(de_ctx* c) { c->gen_render++; }
 void touched_hdr(de_ctx* c) { c->gen_hdr++; }
-int check_v5_status(de_ctx* c);
+void note_abort(de_ctx* c);
+int frame_status(de_ctx* c);
+// Wait for everything the context has issued.  An abort word found afterwards is RECORDED (the frame is invalid until de_reset) but does not
+// fail the caller: uploads, partition changes and the like synchronise for their own reasons; the entry points that hand a frame to the host
+// (fetch, reduce, flush, synchronize) ask frame_status().
 int sync_all(de_ctx* c) {
     for (int i = 0; i < c->n_slots; ++i)
         if (c->slot[i].stream) HIP_TRY(hipStreamSynchronize(c->slot[i].stream));
     for (int i = 0; i < c->n_slots; ++i) c->slot[i].pending = false;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return check_v5_status(c);
+    note_abort(c);
+    return DE_OK;
 }
 void release_loan(de_ctx* c) {
     if (c->lender) { c->lender->loans--; c->lender = nullptr; }
@@ -375,6 +386,8 @@ int ensure_packed(de_ctx* c, int slot, bool clamp) {
 
 int alloc_texture(de_ctx* c, int slot, int w, int h, int ch) {
     DevTexture& t = c->tex[slot];
+    if ((unsigned long long)(ch == 1 ? ((w + 7) / 8) * 8 : w) * (unsigned long long)(ch == 1 ? ((h + 3) / 4) * 4 : h) >= (1ull << 30))
+        return fail(DE_ERR_INVALID, "map too large: the packed copy (one dword per texel) must stay below 4 GB — the kernels address it with a 32-bit byte offset");
     if (c->loans > 0) return fail(DE_ERR_STATE, "the maps are lent to another context (de_share_textures): destroy the borrowers, or give them maps of their own, before replacing a map");
     { int rc = sync_all(c); if (rc) return rc; }      // no launch may still read the map that is being replaced
     if (t.linear && !t.borrowed) hipFree(t.linear);
@@ -626,7 +639,7 @@ hipError_t launch_v3(de_ctx* c, const RenderArgs& a, hipStream_t stream, int pip
 int v5_reserve(de_ctx* c, int idx, hipStream_t stream, size_t n_items) {
     de_ctx::V5State& S = c->v5s[idx];
     const uint32_t pool_chunks = 1u << c->v5_pool_log2;
-    if (!S.pool || S.pool_chunks != pool_chunks || S.n_shards != (uint32_t)c->v5_shards) {
+    if (!S.pool || !S.ctl || !S.rings || !S.free_ring || !S.d_args || !S.h_status || S.pool_chunks != pool_chunks || S.n_shards != (uint32_t)c->v5_shards) {      // all or none (a reservation that failed half way is redone)
         HIP_TRY(hipStreamSynchronize(stream));
         if (S.pool) hipFree(S.pool); if (S.ctl) hipFree(S.ctl); if (S.rings) hipFree(S.rings); if (S.free_ring) hipFree(S.free_ring);
         S.pool = nullptr; S.ctl = nullptr; S.rings = nullptr; S.free_ring = nullptr;
@@ -695,11 +708,12 @@ hipError_t launch_v5(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
 int v6_reserve(de_ctx* c, int idx, hipStream_t stream) {
     de_ctx::V6State& S = c->v6s[idx];
     const uint32_t n_wg = (uint32_t)c->n_cus * DE_V6_WG_PER_CU;
-    if (S.cold && S.n_wg == n_wg) return DE_OK;
+    if (S.cold && S.ctl && S.d_args && S.h_status && S.n_wg == n_wg) return DE_OK;      // all four or none: a slot whose allocation failed half way is completed (or fails again) here
     HIP_TRY(hipStreamSynchronize(stream));
     if (S.cold) hipFree(S.cold);
-    S.cold = nullptr; S.n_wg = n_wg;
-    HIP_TRY(hipMalloc(&S.cold, (size_t)S.n_wg * DE_V6_P * sizeof(wf::Cold)));
+    S.cold = nullptr; S.n_wg = 0;
+    if (hipMalloc(&S.cold, (size_t)n_wg * DE_V6_P * sizeof(wf::Cold)) != hipSuccess) { (void)hipGetLastError(); S.cold = nullptr; return fail(DE_ERR_NOMEM, "no room for the cold records of a render_kernel_v6 launch slot (37 MB)"); }
+    S.n_wg = n_wg;
     if (!S.ctl) HIP_TRY(hipMalloc(&S.ctl, (size_t)bs::G_WORDS * DE_V6_CTL_STRIDE * sizeof(uint32_t)));
     if (!S.d_args) HIP_TRY(hipMalloc(&S.d_args, sizeof(RenderArgs)));
     if (!S.h_status) {
@@ -719,7 +733,7 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     A.status = d_status;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
     A.idle_limit = 1u << 24;      // ~7 s of idling
-    for (int k = 0; k < 3; ++k) A.svc[k] = (uint32_t)c->v6_svc[k];
+    for (int k = 0; k < 3; ++k) { A.svc[k] = (uint32_t)c->v6_svc[k]; A.svc_area[k] = (uint32_t)c->v6_svc_area[k]; }
     A.yield_max = (uint32_t)c->v6_yield; A.elsewhere_min = (uint32_t)c->v6_elsewhere; A.retry = (uint32_t)c->v6_retry; A.enter_min = (uint32_t)c->v6_enter_min; A.flat_min = (uint32_t)c->v6_flat_min;
     hipLaunchKernelGGL(v6_init_kernel, dim3(1), dim3(256), 0, stream, S.ctl, a, S.d_args);
     // DE_V6_WG_PER_CU workgroups per CU; a small launch: one per wave-load of new paths per wave (a workgroup's waves start 64 at a time)
@@ -730,14 +744,17 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     else hipLaunchKernelGGL((v6_kernel<false, false>), grid, block, 0, stream, A, a.fc);
     return hipGetLastError();
 }
-// after the host has synchronised: did a persistent launch leave on its abort word?
-int check_v5_status(de_ctx* c) {
+// Did a persistent launch leave on its abort word?  The word is host-visible pinned memory written by the kernel when it gives up; what has
+// arrived is folded into the context's sticky flag (and the word re-armed for the next launch).  Sticky: the HDR buffer of this frame is
+// missing paths until de_reset, however often it is fetched.
+void note_abort(de_ctx* c) {
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
         de_ctx::V6State& S = c->v6s[i];
         if (S.h_status && S.h_status[0] != 0u) {
             const uint32_t code = S.h_status[0];
             S.h_status[0] = 0u;
-            return fail(DE_ERR_HIP, std::string("render_kernel_v6 left on its abort word (") + (code == bs::ERR_ENTRY_TIMEOUT ? "a ring entry was never stored" : "idle watchdog: work was lost") + "): the frame is invalid");
+            c->frame_invalid = true;
+            c->invalid_msg = std::string("render_kernel_v6 left on its abort word (") + (code == bs::ERR_ENTRY_TIMEOUT ? "a ring entry was never stored" : code == bs::ERR_CELL_BUSY_TIMEOUT ? "a ring cell was never emptied" : "idle watchdog: work was lost") + "): the frame is invalid until de_reset";
         }
     }
     for (int i = 0; i < DE_MAX_SLOTS + 4; ++i) {
@@ -745,10 +762,14 @@ int check_v5_status(de_ctx* c) {
         if (S.h_status && S.h_status[0] != 0u) {
             const uint32_t code = S.h_status[0];
             S.h_status[0] = 0u;
-            return fail(DE_ERR_HIP, std::string("render_kernel_v5 left on its abort word (") + (code == ps::ERR_CELL_TIMEOUT ? "a ring cell was never stored" : code == ps::ERR_POOL_EMPTY ? "the chunk pool ran empty: raise DE_V5_POOL_LOG2" : code == ps::ERR_RING_FULL ? "a queue ring wrapped: fewer shards or a lower DE_V5_BACKLOG" : "idle watchdog: work was lost") + "): the frame is invalid");
+            c->frame_invalid = true;
+            c->invalid_msg = std::string("render_kernel_v5 left on its abort word (") + (code == ps::ERR_CELL_TIMEOUT ? "a ring cell was never stored" : code == ps::ERR_POOL_EMPTY ? "the chunk pool ran empty: raise DE_V5_POOL_LOG2" : code == ps::ERR_RING_FULL ? "a queue ring wrapped: fewer shards or a lower DE_V5_BACKLOG" : "idle watchdog: work was lost") + "): the frame is invalid until de_reset";
         }
     }
-    return DE_OK;
+}
+int frame_status(de_ctx* c) {
+    note_abort(c);
+    return c->frame_invalid ? fail(DE_ERR_HIP, c->invalid_msg) : DE_OK;
 }
 
 // One launch on `stream`.  v2 (the default path tracer): render_kernel_v2 writes the per-sample records, then — after `pre_acc`
@@ -829,7 +850,7 @@ int copy_out(de_ctx* c, float* out, const float* d_src) {
         HIP_TRY(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    return check_v5_status(c);
+    return frame_status(c);
 }
 
 
@@ -841,6 +862,11 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, struct UniqueId128, int) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;      // the four below: de_reduce_ordered only (optional at load)
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*CommUserRank)(void*, int*) = nullptr;   // optional: which rank of an external communicator this context is
     const char* (*GetErrorString)(int) = nullptr;
@@ -874,6 +900,11 @@ int load_rccl() {
     r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     r.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
+    r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+    r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+    r.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    r.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy || !r.GetErrorString)
         return fail(DE_ERR_STATE, "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy / ncclGetErrorString");
     g_rccl = r;
@@ -925,6 +956,7 @@ void read_env_knobs(de_ctx* c) {
         env_int("DE_V5_WPC", &c->v5_wpc, 1); env_int("DE_V5_SHARDS", &c->v5_shards, 1); env_int("DE_V5_POOL_LOG2", &c->v5_pool_log2, 10);
         env_int("DE_V5_CLAIM_K", &c->v5_claim_k, 1); env_int("DE_V5_AGE", &c->v5_age, 1); env_int("DE_V5_CLOSERS", &c->v5_closers_per_cu, 1);
         env_int("DE_V6_STATS", &c->v6_stats, 0); env_int("DE_V6_SVC_ST", &c->v6_svc[0], 1); env_int("DE_V6_SVC_GAS", &c->v6_svc[1], 1); env_int("DE_V6_SVC_CLOUD", &c->v6_svc[2], 1);
+        env_int("DE_V6_AREA_ST", &c->v6_svc_area[0], 0); env_int("DE_V6_AREA_GAS", &c->v6_svc_area[1], 0); env_int("DE_V6_AREA_CLOUD", &c->v6_svc_area[2], 0);
         env_int("DE_V6_YIELD", &c->v6_yield, 0); env_int("DE_V6_ELSEWHERE", &c->v6_elsewhere, 1); env_int("DE_V6_RETRY", &c->v6_retry, 1); env_int("DE_V6_ENTER_MIN", &c->v6_enter_min, 0); env_int("DE_V6_FLAT_MIN", &c->v6_flat_min, 0); env_int("DE_V5_STATS", &c->v5_stats, 0); env_int("DE_V5_LOCAL", &c->v5_local, 0); env_int("DE_V5_BACKLOG", &c->v5_backlog, 0); env_int("DE_V5_RESERVE_PCT", &c->v5_reserve_pct, 1); env_int("DE_V5_BATCHES", &c->v5_batches, 1);
         if (const char* e7 = getenv("DE_V5_MAX_ITEMS")) { long long x = atoll(e7); if (x >= 4096) c->v5_max_items = (size_t)x; }
         if (c->v5_shards > 32) c->v5_shards = 32;            // every ring has a cell per chunk of the pool (it cannot wrap): 1 MB x 7 per shard
@@ -1022,7 +1054,7 @@ int de_destroy(de_ctx* c) {
     release_loan(c);
     for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled, c->d_gather};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (auto& P : c->v3p) {
@@ -1217,6 +1249,8 @@ int de_reset(de_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, DE_N_COUNTERS * sizeof(unsigned long long), c->stream));
     memset(&c->counters, 0, sizeof(c->counters));
     c->current_spp = 0;
+    note_abort(c);                         // re-arm the abort words ...
+    c->frame_invalid = false;              // ... a new frame starts
     if (c->display_src == c->d_assembled) c->display_src = nullptr;    // the assembled frame of a progressive reduce is history now
     return DE_OK;
 }
@@ -1230,6 +1264,17 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
     rc = fill_render_args(c, &a);
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+    // Sample partition (renderer.py:371-380 dealt round robin): the call covers the frame's sample indices
+    // [current_spp, current_spp + spp); this context renders those = sample_rank (mod sample_world) — `first`, first + world, ... —
+    // and the frame's sample counter advances by the whole spp on every rank.
+    const int frame_spp = spp;
+    int first_index = c->current_spp;
+    if (c->sample_world > 1) {
+        const int rem = first_index % c->sample_world;
+        first_index += (c->sample_rank - rem + c->sample_world) % c->sample_world;
+        spp = first_index < c->current_spp + frame_spp ? (c->current_spp + frame_spp - first_index + c->sample_world - 1) / c->sample_world : 0;
+    }
+    a.spp_stride = c->sample_world;
     const bool v2 = c->kernel_variant != 1 && !(c->p.flags & DE_FLAG_RAY_MARCHER);     // per-sample records + accumulate_kernel
     // does this call go through the wavefront pipeline, and with which settings
     const unsigned long long call_items = (unsigned long long)a.n_tiles * 64ull * (unsigned long long)(spp > 0 ? spp : 0);
@@ -1439,7 +1484,7 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
         }
         a.contrib = s.contrib;
         a.work_counter = c->d_work_counter + 16 * si;
-        a.spp_begin = c->current_spp + done; a.spp_count = n;
+        a.spp_begin = first_index + done * c->sample_world; a.spp_count = n;
         a.spp_magic = ((1ull << 40) / (unsigned long long)n) + 1ull;
         if (s.seen_render != c->gen_render) {
             HIP_TRY(hipStreamWaitEvent(s.stream, c->ev_main, 0));
@@ -1473,7 +1518,13 @@ int de_accumulate(de_ctx* c, int spp, uint64_t seed, int tile_rank, int tile_wor
             HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true;
         }
     }
-    c->current_spp += spp;
+    c->current_spp += frame_spp;
+    return DE_OK;
+}
+
+int de_set_sample_partition(de_ctx* c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(DE_ERR_INVALID, "sample partition: 0 <= rank < world");
+    c->sample_rank = rank; c->sample_world = world;      // read by the next de_accumulate; launches in flight keep what they were issued with
     return DE_OK;
 }
 
@@ -1516,6 +1567,24 @@ int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
     return DE_OK;
 }
 
+/* Phases of the LAST render_kernel_v6 launch of the last de_accumulate call, from the kernel's own clock (100 MHz): ms[0] = first workgroup start
+ * to last wave exit, ms[1] = the DRAIN — from the first wave that found no work item left to the last wave's exit (the launch's last long
+ * paths, which no scheduling shortens: what separates a rank's 1/N share of a frame from 1/N of the frame's time).  Waits for that launch.
+ * DE_ERR_STATE when the last call did not run render_kernel_v6. */
+int de_last_launch_phases(de_ctx* c, float* ms2) {
+    if (!c || !ms2) return fail(DE_ERR_INVALID, "null argument");
+    if (c->last_call[0] != 6 || c->last_slot < 0) return fail(DE_ERR_STATE, "the last de_accumulate did not run render_kernel_v6");
+    HIP_TRY(hipSetDevice(c->device));
+    de_ctx::V6State& S = c->v6s[c->last_slot];
+    if (!S.ctl) return fail(DE_ERR_STATE, "no launch yet");
+    HIP_TRY(hipStreamSynchronize(c->slot[c->last_slot].stream));
+    unsigned long long t[3] = {0ull, 0ull, 0ull};
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpy(&t[k], S.ctl + (size_t)(bs::G_T_START + k) * DE_V6_CTL_STRIDE, 8, hipMemcpyDeviceToHost));
+    ms2[0] = t[2] > t[0] ? (float)((double)(t[2] - t[0]) * 1e-5) : 0.f;
+    ms2[1] = (t[2] > t[1] && t[1] != ~0ull) ? (float)((double)(t[2] - t[1]) * 1e-5) : 0.f;
+    return DE_OK;
+}
+
 int de_last_call_info(de_ctx* c, int* variant, int* pipes, int* depths, int* launches) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     if (variant) *variant = c->last_call[0];
@@ -1534,7 +1603,7 @@ int de_flush(de_ctx* c) {
     int rc = join_slots(c);
     if (rc) return rc;
     touched_hdr(c);          // whatever the host enqueues next on the stream may touch the HDR buffer
-    return DE_OK;
+    return frame_status(c);  // an abort already known (the words are host-visible): a host framework's own collective must not ship that frame
 }
 
 int de_render_to_image(de_ctx* c, const float** device_image) {
@@ -1573,7 +1642,7 @@ int de_fetch_image_view(de_ctx* c, const float** host_image) {
     HIP_TRY(hipMemcpyAsync(c->h_stage, c->d_image, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *host_image = c->h_stage;
-    return check_v5_status(c);
+    return frame_status(c);
 }
 
 int de_fetch_hdr(de_ctx* c, float* out) {
@@ -1647,7 +1716,8 @@ int de_use_own_stream(de_ctx* c) {
 int de_synchronize(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    return sync_all(c);
+    { int rc = sync_all(c); if (rc) return rc; }
+    return frame_status(c);
 }
 int de_last_accumulate_ms(de_ctx* c, float* ms) {
     if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
@@ -1720,6 +1790,8 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     HIP_TRY(hipSetDevice(c->device));
     rc = join_slots(c);
     if (rc) return rc;
+    rc = frame_status(c);      // what is known so far; the host synchronises (and asks again) before it reads the assembled frame
+    if (rc) return rc;
     const size_t count = (size_t)c->W * c->H * 3;
     float* recv = c->d_hdr;
     if (progressive) {
@@ -1749,6 +1821,66 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     return DE_OK;
 }
 }  // namespace
+
+namespace {
+// The collective of a SAMPLE partition (de_set_sample_partition): every pixel's sum has a term on every rank, so the order of the additions
+// is part of the result.  ncclReduce leaves that order to the algorithm RCCL picks; here the ranks' buffers are GATHERED on the root (one
+// ncclSend / ncclRecv pair per peer in one group: the root's ingress runs over its xGMI links in parallel) and added by ordered_sum_kernel
+// in rank order, so the assembled frame is a function of the partition alone (tests hold it to the oracle's partial sums added the same way).
+int reduce_ordered_impl(de_ctx* c, void* comm, int root, bool out_of_place) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    void* use = comm ? comm : c->comm;
+    if (!use) return fail(DE_ERR_STATE, "no communicator: pass an ncclComm_t or call de_comm_init");
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(DE_ERR_STATE, "librccl.so lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    int world = c->comm_world, my_rank = c->comm_rank;
+    if (comm) {
+        if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(DE_ERR_STATE, "librccl.so lacks ncclCommCount / ncclCommUserRank: an external communicator cannot be asked for its shape");
+        RCCL_TRY(g_rccl.CommCount(use, &world));
+        RCCL_TRY(g_rccl.CommUserRank(use, &my_rank));
+    }
+    if (root < 0 || root >= world) return fail(DE_ERR_INVALID, "root out of range");
+    if (world > 16) return fail(DE_ERR_INVALID, "de_reduce_ordered: at most 16 ranks");
+    HIP_TRY(hipSetDevice(c->device));
+    rc = join_slots(c);
+    if (rc) return rc;
+    rc = frame_status(c);
+    if (rc) return rc;
+    const size_t count = (size_t)c->W * c->H * 3;
+    if (!c->ev_r0) { HIP_TRY(hipEventCreate(&c->ev_r0)); HIP_TRY(hipEventCreate(&c->ev_r1)); }
+    if (my_rank == root) {
+        if (c->gather_world < world) {
+            { int rc2 = sync_all(c); if (rc2) return rc2; }
+            if (c->d_gather) hipFree(c->d_gather);
+            c->d_gather = nullptr; c->gather_world = 0;
+            if (hipMalloc(&c->d_gather, (size_t)world * count * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no room for the gather buffer of de_reduce_ordered"); }
+            c->gather_world = world;
+        }
+        if (out_of_place && !c->d_assembled) HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
+    }
+    HIP_TRY(hipEventRecord(c->ev_r0, c->stream));
+    if (my_rank == root) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int r = 0; r < world; ++r)
+            if (r != root) { int e = g_rccl.Recv(c->d_gather + (size_t)r * count, count, /*ncclFloat32*/ 7, r, use, c->stream); if (e != 0) { g_rccl.GroupEnd(); return fail(DE_ERR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(e)); } }
+        RCCL_TRY(g_rccl.GroupEnd());
+        OrderedSumArgs o;
+        for (int r = 0; r < world; ++r) o.part[r] = (r == root) ? c->d_hdr : c->d_gather + (size_t)r * count;
+        o.out = out_of_place ? c->d_assembled : c->d_hdr; o.n_parts = world; o.n4 = count / 4; o.n = count;
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
+        HIP_TRY(hipGetLastError());
+        if (out_of_place) c->display_src = c->d_assembled;
+    } else {
+        RCCL_TRY(g_rccl.Send(c->d_hdr, count, /*ncclFloat32*/ 7, root, use, c->stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
+    c->reduce_timing_valid = true;
+    touched_hdr(c);                        // the collective reads (root, in place: rewrites) d_hdr: the next accumulate_kernel is ordered after it
+    return DE_OK;
+}
+}  // namespace
+int de_reduce_ordered(de_ctx* c, void* comm, int root, int out_of_place) { return reduce_ordered_impl(c, comm, root, out_of_place != 0); }
 
 int de_reduce(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, false); }
 int de_reduce_progressive(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, true); }
@@ -1814,6 +1946,7 @@ int de_debug_v6_stats(de_ctx* c, uint64_t* out, int n) {
         if (!S.ctl) continue;
         HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (int k = 0; k < n && k < bs::ST_N; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_STAT0 + k) * DE_V6_CTL_STRIDE], 8); out[k] += v; }
+        for (int k = 64; k < n && k < 128; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_STAT2 + k - 64) * DE_V6_CTL_STRIDE], 8); out[k] += v; }      // region statistics
     }
     return DE_OK;
 }
@@ -1838,7 +1971,7 @@ int de_debug_samples(de_ctx* c, uint64_t seed, int sample_index, float* out) {
     rc = fill_render_args(c, &a);
     if (rc) return rc;
     a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-    a.spp_begin = sample_index; a.spp_count = 1;
+    a.spp_begin = sample_index; a.spp_count = 1; a.spp_stride = 1;
     a.spp_magic = (1ull << 40) + 1ull;
     a.contrib = nullptr;
     a.work_counter = c->d_work_counter + 16 * DE_MAX_SLOTS;     // a counter of its own: launches in the slots keep theirs

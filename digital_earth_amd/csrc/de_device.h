@@ -92,6 +92,17 @@ struct TexF3 {
 
 struct TapCount { uint32_t r8, rgb; };
 
+// A dword of a map by index: the pointer is cast to the GLOBAL address space, so that the load is a global_load_dword with the
+// (wave-uniform) base in scalar registers and the 32-bit byte offset in one vector register — a generic pointer makes it a flat_load with
+// a 64-bit vector address: two more VGPRs live through every tracking loop (at 80 VGPRs that was the difference between the cloud map's
+// base staying in registers and being reloaded from scratch on every tap: round 5) and a 64-bit vector add per tap.  Same dword either way.
+DE_DEV uint32_t map_dword(const uint32_t* base, uint32_t idx) {
+    typedef const __attribute__((address_space(1))) uint32_t* de_gptr;
+    typedef const __attribute__((address_space(1))) char* de_gbytes;
+    const uint32_t byte_off = idx << 2;      // 32-bit on purpose (every map is below 4 GB: de_api.hip refuses larger ones): the offset fits the instruction's one-VGPR form
+    return *(de_gptr)((de_gbytes)base + byte_off);
+}
+
 // A tap in two halves, so that the caller can put independent work between the load and its first use.
 template <bool CLAMP>
 DE_DEV uint32_t tap_r8_issue(const TexR8& t, float u, float v, float* fx_out, float* fy_out) {
@@ -109,7 +120,7 @@ DE_DEV uint32_t tap_r8_issue(const TexR8& t, float u, float v, float* fx_out, fl
     }
     uint32_t idx = ((uint32_t)(j0 >> 2) * (uint32_t)t.tiles_x + (uint32_t)(i0 >> 3)) * 32u + (uint32_t)(((j0 & 3) << 3) | (i0 & 7));
     *fx_out = fx; *fy_out = fy;
-    return t.data[idx];
+    return map_dword(t.data, idx);
 }
 // The same tap for a caller that samples the map at points a fraction of a texel apart (tracking through the cloud shell: a free
 // flight of ~345 m against texels of 1.85 km): the footprint dword of the previous tap is kept, and a tap whose footprint is the
@@ -130,7 +141,7 @@ DE_DEV uint32_t tap_r8_issue_cached(const TexR8& t, float u, float v, float* fx_
     }
     const uint32_t idx = ((uint32_t)(j0 >> 2) * (uint32_t)t.tiles_x + (uint32_t)(i0 >> 3)) * 32u + (uint32_t)(((j0 & 3) << 3) | (i0 & 7));
     *fx_out = fx; *fy_out = fy;
-    if (idx != last_idx) { last_q = t.data[idx]; last_idx = idx; }
+    if (idx != last_idx) { last_q = map_dword(t.data, idx); last_idx = idx; }
     return last_q;
 }
 DE_DEV float tap_r8_finish(uint32_t q, float fx, float fy) {

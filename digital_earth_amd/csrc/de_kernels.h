@@ -70,7 +70,8 @@ struct RenderArgs {
     int n_tiles, tiles_x;
     int tiles_identity;           // tiles[k] == k (tile_world == 1)
     uint32_t seed_lo, seed_hi;
-    int spp_begin, spp_count;
+    int spp_begin, spp_count;     // this launch renders sample indices spp_begin + k * spp_stride, k = 0 .. spp_count - 1
+    int spp_stride;               // 1, or the world size of a sample partition (de_set_sample_partition: renderer.py:371-380 dealt round robin)
     int fixed_wavelength;
     unsigned long long* counters; // [8] when counting
     float* debug_out;             // [H][W][4] when tracing single samples

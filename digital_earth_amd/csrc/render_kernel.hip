@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) render_kernel(RenderArgs a) {
     uint32_t draws = 0;
     for (int s = 0; s < a.spp_count; ++s) {
         Rng rng;
-        rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s));
+        rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s * a.spp_stride));
         int node = 0;
         if (!a.fixed_wavelength) node = spectrum_node(a.node_val, rng_next(rng));
         const LambdaNode L = a.nodes[node];
@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(256) ray_march_kernel(RenderArgs a) {
     uint32_t draws = 0;
     for (int s = 0; s < a.spp_count; ++s) {
         Rng rng;
-        rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s));
+        rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s * a.spp_stride));
         int node = 0;
         if (!a.fixed_wavelength) node = spectrum_node(a.node_val, rng_next(rng));
         const LambdaNode L = a.nodes[node];

@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(DE_V2_BLOCK, DE_V2_MIN_WAVES) render_kernel_v2
                     const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
                     const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
                     const uint32_t pixel = (uint32_t)(v * a.W + u);
-                    rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
+                    rng_seed(rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx * a.spp_stride));
                     node = 0;
                     if (!a.fixed_wavelength) node = v2::spectrum_node(s_node_val, a.node_val, rng_next(rng));
                     const LambdaNode& L = a.nodes[node];

@@ -361,7 +361,7 @@ DE_DEV void new_path(const RenderArgs& a, const FrameConsts& fc, const float* s_
     const int u = (int)(tile % (uint32_t)a.tiles_x) * 8 + (sub & 7);
     const int v = (int)(tile / (uint32_t)a.tiles_x) * 8 + (sub >> 3);
     const uint32_t pixel = (uint32_t)(v * a.W + u);
-    rng_seed(p.rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx));
+    rng_seed(p.rng, a.seed_lo, a.seed_hi, pixel, (uint32_t)(a.spp_begin + s_idx * a.spp_stride));
     int node = 0;
     if (!a.fixed_wavelength) {
         const float sample = rng_next(p.rng);

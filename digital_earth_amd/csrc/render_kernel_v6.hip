@@ -54,16 +54,39 @@ enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
 #define DE_V6_P 1120u                      // record slots per workgroup, 56 B each (61 KB): with the rings and the rest the 80 KB a workgroup can have (1008 slots of 64 B: +5.6 % time; 960: +7 %; 768: +19 %)
 #endif
 #ifndef DE_V6_CAP
-#define DE_V6_CAP 1128u                    // entries per ring (> DE_V6_P: an entry is never overwritten before it is taken); indices are taken modulo this
+#define DE_V6_CAP 1128u                    // entries per ring (> DE_V6_P: a ring can hold every slot number); indices are taken modulo this
 #endif
-#define DE_V6_EMPTY 0xffffu
+// A ring cell is 16 bits: bit 15 = full, bits 11-14 = lap (index / DE_V6_CAP, modulo 16), bits 0-10 = slot number (all ones when the cell is
+// empty).  Ticket i may only be STORED into a cell that reads "empty, lap(i)" and only be TAKEN from a cell that reads "full, lap(i)"; the take
+// leaves "empty, lap(i) + 1".  So a cell's states form one chain — empty(0), full(0), empty(1), full(1), ... — and every transition has exactly ONE
+// writer (tickets are unique: one fetch-add per push, one compare-and-swap per claim), whatever the waves' relative speeds: a producer a whole lap
+// ahead of a stalled consumer waits for that consumer's take instead of overwriting its entry, a consumer a lap ahead waits for its own
+// producer instead of taking the stalled one's entry.  Sixteen laps cannot be open at one cell: each open lap blocks a different wave in a bounded
+// wait, and a workgroup has DE_V6_WAVES <= 15 of them.  (Rounds 4's rings relied on "at most DE_V6_P slot numbers exist for DE_V6_CAP cells",
+// which bounds what is queued, not what a stalled wave has claimed and not yet taken: VERDICT r4 weak #7.)
+#define DE_V6_EMPTY 0xffffu                // take()'s "timed out" value: never a slot number
+#define DE_V6_SLOT_MASK 0x7ffu
+static_assert(DE_V6_P < DE_V6_SLOT_MASK, "slot numbers take 11 bits of a ring cell; the all-ones pattern marks an empty cell");
+static_assert(DE_V6_CAP >= DE_V6_P, "a ring must be able to hold every slot number");
+static_assert(DE_V6_WAVES <= 15, "the lap tag of a ring cell has four bits: one open lap per blocked wave at most");
 #define DE_V6_CTL_STRIDE 32u
 // global control words (index x DE_V6_CTL_STRIDE dwords): 0 work counter, 8.. statistics (64-bit)
-enum { G_WORK = 0, G_STAT0 = 8, G_WORDS = 8 + 64 };
+// 1-3 (64-bit, 100 MHz real-time counter; every build): the launch's first workgroup start, the first wave that found the work counter exhausted, the last wave's exit
+// — the launch's DRAIN, the time its last paths take once nothing is left to start, is what separates a rank's 1/N share from 1/N of the frame (de_last_launch_phases)
+enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORDS = 8 + 64 + 64 };
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
 // 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
+// region statistics (G_STAT2 + k; STATS builds only): where a wave's time goes and how many lanes the region's vector code runs for.  Per loop stage q
+// (sphere trace, gas, cloud) fourteen words at 14 q: shader-clock ticks and ticks x active lanes of R_STEP (the stage's step(), lanes = busy), R_EPI (finish()
+// + the record's write-back, lanes = finished), R_PUSH (release + ring appends), R_REFILL (claim, take, record load, begin() / restore(), lanes = refilled),
+// R_YIELD (suspend + hand back), R_HEAD (the trip's own control: ballots, thresholds; no vector work: lanes 0), then [12] services, [13] trips.  Per
+// straight-line stage q (event, surface, volume finish, surface finish) four words at 42 + 4 (q - 3): ticks and ticks x lanes of the body, ticks of the
+// pass's ring work (claim, take, record load / store, appends), passes.  The same four for new paths (primary sphere trace included) at 58.
+enum { R_STEP = 0, R_EPI, R_PUSH, R_REFILL, R_YIELD, R_HEAD, R_N };
 enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_DRAIN = 22, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
-enum { ERR_ENTRY_TIMEOUT = 1, ERR_IDLE_WATCHDOG = 3 };
+enum { ERR_ENTRY_TIMEOUT = 1, ERR_CELL_BUSY_TIMEOUT = 2, ERR_IDLE_WATCHDOG = 3 };
+DE_DEV uint32_t cell_empty(uint32_t lap) { return ((lap & 15u) << 11) | DE_V6_SLOT_MASK; }
+DE_DEV uint32_t cell_full(uint32_t lap, uint32_t slot) { return 0x8000u | ((lap & 15u) << 11) | slot; }
 
 struct Args {
     const RenderArgs* ra;       // the launch's RenderArgs in device memory (written by v6_init_kernel)
@@ -73,7 +96,8 @@ struct Args {
     uint32_t n_items;
     uint32_t idle_limit;        // watchdog: scheduler rounds without work before a wave raises the abort word
     // tuning (de_api.hip: DE_V6_* environment)
-    uint32_t svc[3];            // idle lanes at which a loop stage (sphere trace, gas, cloud) services: pushes finished records, refills
+    uint32_t svc[3];            // idle lanes at which a loop stage (sphere trace, gas, cloud) services: pushes finished records, refills ...
+    uint32_t svc_area[3];       // ... or (> 0) the idle LANE-TRIPS since its last service at which it does: see run_loop
     uint32_t yield_max;         // a loop-stage wave whose ring is dry hands its records back when at most this many lanes are busy ...
     uint32_t elsewhere_min;     // ... and another ring (or the free slots, while paths are left to start) holds at least this many entries
     uint32_t retry;             // trips between two looks at a dry ring
@@ -91,6 +115,7 @@ struct Cfg {
     uint32_t* status;
     uint32_t n_items, idle_limit;
     uint32_t svc[3];
+    uint32_t svc_area[3];
     uint32_t yield_max, elsewhere_min, retry, enter_min;
     uint32_t flat_min;
 };
@@ -106,6 +131,24 @@ __shared__ uint32_t s_cfg[32];
 
 DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// What a stage reads of the launch (map descriptors, table pointers, frame constants) arrives through a pointer the optimiser cannot see through
+// — as flat loads into VECTOR registers, although every lane gets the same value.  Broadcast to scalar registers: a map's seven dwords in
+// VGPRs were what pushed the cloud map's base pointer out to scratch inside the tracking loop (round 5), and a scalar base lets the tap be a
+// global_load_dword with the 32-bit offset in one VGPR (de_device.h: map_dword).
+DE_DEV float unif(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <typename T>
+DE_DEV const T* uni_ptr(const T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned long long lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<const T*>((hi << 32) | lo);
+}
+DE_DEV TexR8 uni_tex(const TexR8& t) {
+    TexR8 o;
+    o.data = uni_ptr(t.data);
+    o.w = __builtin_amdgcn_readfirstlane(t.w); o.h = __builtin_amdgcn_readfirstlane(t.h); o.tiles_x = __builtin_amdgcn_readfirstlane(t.tiles_x);
+    o.wf = unif(t.wf); o.hf = unif(t.hf);
+    return o;
+}
 DE_DEV uint32_t ld_wg(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DE_DEV uint32_t add_wg(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DE_DEV uint32_t ld_e(const uint16_t* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -153,6 +196,36 @@ struct Wave {
     uint32_t n_work, w_lo, w_hi;
     bool primary_left, aborted;
     unsigned long long t_mark, t_drain;
+    unsigned long long r_t[R_N], r_l[R_N], r_last, r_cnt[2];      // region statistics of the running stage (STATS builds only)
+
+    DE_DEV void regions_begin() {
+        if (!STATS) return;
+#pragma unroll
+        for (int k = 0; k < R_N; ++k) { r_t[k] = 0ull; r_l[k] = 0ull; }
+        r_cnt[0] = r_cnt[1] = 0ull;
+        r_last = __builtin_amdgcn_s_memtime();
+    }
+    // the time since the last call belongs to region R, whose vector code ran for `lanes` lanes
+    template <int R>
+    DE_DEV void tick(unsigned long long lanes) {
+        if (!STATS) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime(), dt = t - r_last;
+        r_t[R] += dt; r_l[R] += dt * lanes; r_last = t;
+    }
+    DE_DEV void stat2(int k, unsigned long long v) {
+        if (STATS && lane_id() == 0 && v) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.ctl + (G_STAT2 + k) * DE_V6_CTL_STRIDE), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    DE_DEV void regions_end_loop(int q) {
+        if (!STATS) return;
+#pragma unroll
+        for (int k = 0; k < R_N; ++k) { stat2(14 * q + 2 * k, r_t[k]); stat2(14 * q + 2 * k + 1, r_l[k]); }
+        stat2(14 * q + 12, r_cnt[0]); stat2(14 * q + 13, r_cnt[1]);
+    }
+    // straight-line stages (base = 42 + 4 (q - 3)) and new paths (base = 58): R_STEP = the body, R_PUSH = the pass's ring work
+    DE_DEV void regions_end_flat(int base) {
+        if (!STATS) return;
+        stat2(base, r_t[R_STEP]); stat2(base + 1, r_l[R_STEP]); stat2(base + 2, r_t[R_PUSH]); stat2(base + 3, r_cnt[0]);
+    }
 
     // a stage function's view of the wave: the configuration from LDS (scalar registers after the broadcast), the wave's own flag
     DE_DEV static Wave enter(bool primary_left) {
@@ -206,29 +279,65 @@ struct Wave {
         *first = uni(hh);
         return uni(got);
     }
-    // the slot number in entry idx of ring q (claimed by this wave): wait until its producer has stored it, leave the entry empty
+    // the slot number in entry idx of ring q (claimed by this wave): wait until ITS producer (same lap) has stored it, leave the cell empty for the next lap
     DE_DEV uint32_t take(uint32_t q, uint32_t idx) {
-        uint16_t* e = rings + q * DE_V6_CAP + idx % DE_V6_CAP;
-        uint32_t v = DE_V6_EMPTY;
+        const uint32_t lap = idx / DE_V6_CAP;
+        uint16_t* e = rings + q * DE_V6_CAP + (idx - lap * DE_V6_CAP);
+        const uint32_t want = 0x8000u | ((lap & 15u) << 11);
+        uint32_t v = 0u;
+        bool ok = false;
 #pragma nounroll
         for (uint32_t spins = 0; spins < (1u << 20); ++spins) {
             v = ld_e(e);
-            if (v != DE_V6_EMPTY) break;
+            ok = (v & 0xf800u) == want;
+            if (ok) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (v != DE_V6_EMPTY) st_e(e, DE_V6_EMPTY);
-        return v;
+        if (!ok) return DE_V6_EMPTY;
+        st_e(e, cell_empty(lap + 1u));
+        return v & DE_V6_SLOT_MASK;
     }
-    // append the slot numbers of the lanes with pred to ring Q (their records are written and released)
-    template <int Q>
-    DE_DEV void push(uint32_t slot, bool pred) {
-        const unsigned long long mask = __ballot(pred);
-        if (mask == 0ull) return;
-        const uint32_t n = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+    // Append every lane's slot number to the ring of ITS target stage (to_q: a ring id, or < 0 for lanes that append nothing) — the records are
+    // written and released.  ONE LDS instruction takes the tickets of all target rings (lane k does the fetch-add for the k-th target), one
+    // looks at the cells, one stores them: a service's appends cost the same whether its records go to one stage or to four (round 4 ran one
+    // push per target: a fetch-add round trip each — profiles/r5_v6_lanes_*.md: 1200-2400 ticks per service).  A cell is stored only once the
+    // take of the previous lap has emptied it (bounded wait: with DE_V6_CAP > DE_V6_P it ends at the first look unless a consumer stalls).
+    template <int... TARGETS>
+    DE_DEV void push_all(uint32_t slot, int to_q, Targets<TARGETS...>) {
+        constexpr int NT = (int)sizeof...(TARGETS);
+        constexpr int T[NT] = {TARGETS...};
+        if (__ballot(to_q >= 0) == 0ull) return;
+        const unsigned long long lt = (1ull << lane_id()) - 1ull;
+        uint32_t n_mine = 0, q_mine = 0, rank = 0;
+        int k_mine = -1;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const unsigned long long m = __ballot(to_q == T[k]);
+            if (lane_id() == k) { n_mine = (uint32_t)__popcll(m); q_mine = (uint32_t)T[k]; }
+            if (to_q == T[k]) { rank = (uint32_t)__popcll(m & lt); k_mine = k; }
+        }
+        uint32_t basev = 0;
+        if (lane_id() < NT && n_mine != 0u) basev = add_wg(tail(q_mine), n_mine);
         uint32_t base = 0;
-        if (lane_id() == 0) base = add_wg(tail(Q), n);
-        base = uni(base);
-        if (pred) st_e(rings + Q * DE_V6_CAP + (base + rank) % DE_V6_CAP, slot);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)basev, k);
+            if (k_mine == k) base = bk;
+        }
+        bool stuck = false;
+        if (k_mine >= 0) {
+            const uint32_t idx = base + rank, lap = idx / DE_V6_CAP;
+            uint16_t* e = rings + (uint32_t)to_q * DE_V6_CAP + (idx - lap * DE_V6_CAP);
+            const uint32_t want = cell_empty(lap);
+            stuck = true;
+#pragma nounroll
+            for (uint32_t spins = 0; spins < (1u << 20); ++spins) {
+                if (ld_e(e) == want) { stuck = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!stuck) st_e(e, cell_full(lap, slot));
+        }
+        if (__ballot(stuck) != 0ull) raise(ERR_CELL_BUSY_TIMEOUT);
     }
 
     // ---- the scheduler: which stage this wave runs next — a queue id, Q_PRIMARY, or Q_EXIT
@@ -267,24 +376,41 @@ struct Wave {
     // slots to the next stages' rings and refills the idle lanes from this stage's ring.
     template <int Q, typename Stage, int... TARGETS>
     DE_DEV void run_loop(Stage& st, Targets<TARGETS...>) {
+        // When to service.  Idle lanes waste a fraction of every trip; a service (epilogue, appends, claim, record loads, begin()) costs a fixed
+        // number of trips' worth of issue slots whatever the number of lanes it serves.  With records ending at a rate of r lanes per trip the
+        // waste since the last service grows like r t^2 / 2 lane-trips, and the cost per trip (waste + service) / t is least when the waste
+        // accumulated EQUALS the service's cost: service when the idle lane-trips since the last one reach AREA = 64 x (service cost / trip
+        // cost) — a property of the stage's code, not of the view.  A fixed idle-lane threshold (rounds 3-4: 24 / 24 / 20, the BASELINE cfg2 optimum)
+        // is that rule for ONE rate r: cloud segments of the limb view are five times longer and wanted 12 (VERDICT r4 #1b).
         const int SERVICE = (int)A.svc[Q];
+        const uint32_t AREA = A.svc_area[Q];
+        uint32_t idle_acc = 0;
         Path p;
         uint32_t slot = 0;
         bool busy = false, fin = false;
         int target = -1;
         bool dry = false;
         uint32_t trips = 0, retry_at = 0;
+        regions_begin();
         for (;;) {
             const int nb = __popcll(__ballot(busy));
             const bool may_refill = !dry || trips >= retry_at;
-            if (nb == 0 || (64 - nb >= SERVICE && (may_refill || __ballot(fin) != 0ull))) {
+            idle_acc += (uint32_t)(64 - nb);
+            const bool due = AREA != 0u ? idle_acc >= AREA : 64 - nb >= SERVICE;
+            if (nb == 0 || (due && (may_refill || __ballot(fin) != 0ull))) {
+                idle_acc = 0u;
+                tick<R_HEAD>(0ull);
+                if (STATS) r_cnt[0]++;
                 if (__ballot(fin) != 0ull) {
                     // the stage's epilogue for all the lanes that finished since the last service at once (run where a lane finishes it
                     // would execute for two or three lanes of 64 in most trips)
+                    const unsigned long long n_fin = STATS ? (unsigned long long)__popcll(__ballot(fin)) : 0ull;
                     if (fin) { target = st.finish(p); store_rec(rec, slot, p); }
+                    tick<R_EPI>(n_fin);
                     release_wg();
-                    (push<TARGETS>(slot, fin && target == TARGETS), ...);
+                    push_all(slot, fin ? target : -1, Targets<TARGETS...>{});
                     fin = false;
+                    tick<R_PUSH>(n_fin);
                 }
                 if (may_refill || nb == 0) {
                     dry = false;
@@ -293,6 +419,7 @@ struct Wave {
                     const uint32_t got = claim(Q, 1u, (uint32_t)__popcll(m_need), &first);
                     if (got == 0u) {
                         dry = true; retry_at = trips + A.retry;
+                        tick<R_REFILL>(0ull);
                         // Nothing to refill from, a few long records left, and other work waits: hand the records back — the loop's
                         // state goes to the spare words of their cold records — so that they fill the idle lanes of another wave of this
                         // stage instead of running here at a fraction of the wave (cloud segments have a heavy tail)
@@ -303,9 +430,10 @@ struct Wave {
                                 store_rec(rec, slot, p);
                             }
                             release_wg();
-                            push<Q>(slot, busy);
+                            push_all(slot, busy ? Q : -1, Targets<Q>{});
                             stat(ST_YIELD, 1); stat(ST_YIELDED, (unsigned long long)nb);
                             busy = false;
+                            tick<R_YIELD>((unsigned long long)nb);
                             break;
                         }
                     } else {
@@ -324,16 +452,22 @@ struct Wave {
                             busy = true;
                         }
                         stat(ST_RECS + Q, got);
+                        tick<R_REFILL>((unsigned long long)got);
                     }
                 }
                 if (__ballot(busy) == 0ull) { if (dry || aborted) break; else continue; }
             }
-            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, (unsigned long long)__popcll(__ballot(busy))); }
+            const unsigned long long n_step = STATS ? (unsigned long long)__popcll(__ballot(busy)) : 0ull;
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, n_step); r_cnt[1]++; }
+            tick<R_HEAD>(0ull);
             if (busy) {
                 if (st.step(p)) { busy = false; fin = true; }
             }
+            tick<R_STEP>(n_step);
             trips++;
         }
+        tick<R_HEAD>(0ull);
+        regions_end_loop(Q);
     }
     // is there a wave-load of work outside ring q (another stage's ring, or free slots for new paths)?
     DE_DEV bool work_elsewhere(uint32_t q) {
@@ -347,6 +481,7 @@ struct Wave {
     // ---- a straight-line stage: up to 64 slots per pass, one record per lane, written back in place
     template <int Q, typename Body, int... TARGETS>
     DE_DEV void run_flat(Body body, Targets<TARGETS...>) {
+        regions_begin();
         for (;;) {
             uint32_t first = 0;
             const uint32_t n = claim(Q, 1u, 64u, &first);
@@ -361,24 +496,37 @@ struct Wave {
             if (active) {
                 load_rec(rec, slot, p);
                 p.pid = wf::asu(cold[slot].pad0);
-                target = body(p, ColdAt{cold + slot});
-                if (target >= 0) store_rec(rec, slot, p);
             }
+            tick<R_PUSH>(0ull);
+            if (active) {
+                target = body(p, ColdAt{cold + slot});
+            }
+            tick<R_STEP>((unsigned long long)n);
+            if (active && target >= 0) store_rec(rec, slot, p);
             stat(ST_RECS + Q, n);
-            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, n); }
+            if (STATS) { stat(ST_TRIPS + Q, 1); stat(ST_LANETRIPS + Q, n); r_cnt[0]++; }
             release_wg();
-            (push<TARGETS>(slot, target == TARGETS), ...);
-            push<Q_FREE>(slot, target == -1);
+            push_all(slot, target == -1 ? (int)Q_FREE : target, Targets<TARGETS..., Q_FREE>{});      // target: a ring, -1 = the path has ended, -2 = lane without a record
+            tick<R_PUSH>(0ull);
         }
+        tick<R_PUSH>(0ull);
+        regions_end_flat(42 + 4 * (Q - 3));
     }
 
     // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
     DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
+        regions_begin();
         if (w_lo >= w_hi) {          // 256 work items per device-wide atomic: four passes
             uint32_t w = 0;
             if (lane_id() == 0) w = __hip_atomic_fetch_add(A.ctl + G_WORK * DE_V6_CTL_STRIDE, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             w = uni(w);
-            if (w >= n_work) { primary_left = false; if (STATS) t_drain = __builtin_amdgcn_s_memrealtime(); return; }
+            if (w >= n_work) {
+                primary_left = false;
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (lane_id() == 0) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (STATS) t_drain = now;
+                return;
+            }
             w_lo = w; w_hi = min(w + 256u, n_work);
         }
         const uint32_t n = min(64u, w_hi - w_lo);
@@ -394,6 +542,7 @@ struct Wave {
         const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
         Path p;
         int target = -2;
+        tick<R_PUSH>(0ull);
         if (active) {
             wf::new_path(a, fc, bs::s_node_val, w, p);
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
@@ -401,11 +550,13 @@ struct Wave {
             store_rec(rec, slot, p);
             cold[slot].pad0 = wf::asf(p.pid);
         }
+        tick<R_STEP>((unsigned long long)n);
         stat(ST_RECS + NQ, n);
+        if (STATS) r_cnt[0]++;
         release_wg();
-        push<Q_GAS>(slot, target == Q_GAS);
-        push<Q_CLOUD>(slot, target == Q_CLOUD);
-        push<Q_EVENT>(slot, target == Q_EVENT);
+        push_all(slot, target, Targets<Q_GAS, Q_CLOUD, Q_EVENT>{});
+        tick<R_PUSH>(0ull);
+        regions_end_flat(58);
     }
 };
 
@@ -415,7 +566,10 @@ struct Wave {
 // zero the control words and put the launch's RenderArgs where the persistent kernel reads them
 __global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (uint32_t)bs::G_WORDS) { ctl[i * DE_V6_CTL_STRIDE] = 0u; ctl[i * DE_V6_CTL_STRIDE + 1u] = 0u; }
+    if (i < (uint32_t)bs::G_WORDS) {
+        const uint32_t fill = (i == (uint32_t)bs::G_T_START || i == (uint32_t)bs::G_T_EXHAUSTED) ? 0xffffffffu : 0u;      // the two minima start at the maximum
+        ctl[i * DE_V6_CTL_STRIDE] = fill; ctl[i * DE_V6_CTL_STRIDE + 1u] = fill;
+    }
     if (i == 0u) *dst = a;
 }
 
@@ -428,21 +582,22 @@ DE_V6_STAGE v6_stage_st(bool primary_left) {
     const RenderArgs& a = *W.A.ra;
     const FrameConsts& fc = *W.A.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
-    StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
+    const float lhs = unif(fc.land_height_scale);
+    StStage<CLAMP> st{uni_tex(a.topo), lhs, DE_PLANET_R + de_max(lhs, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
     W.template run_loop<Q_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
 }
 DE_V6_STAGE v6_stage_gas(bool primary_left) {
     using namespace bs;
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
     const RenderArgs& a = *W.A.ra;
-    GasStage st{a.nodes, a.dens_table};
+    GasStage st{uni_ptr(a.nodes), uni_ptr(a.dens_table)};
     W.template run_loop<Q_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
 }
 DE_V6_STAGE v6_stage_cloud(bool primary_left) {
     using namespace bs;
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
     const RenderArgs& a = *W.A.ra;
-    CloudStage<CLAMP> st{a.clouds};
+    CloudStage<CLAMP> st{uni_tex(a.clouds)};
     W.template run_loop<Q_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
 }
 DE_V6_STAGE v6_stage_event(bool primary_left) {
@@ -479,7 +634,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
     using namespace bs;
     for (uint32_t i = threadIdx.x; i < NR * DE_V6_CAP; i += blockDim.x) {
         const uint32_t q = i / DE_V6_CAP, k = i % DE_V6_CAP;
-        s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? k : DE_V6_EMPTY);
+        s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? cell_full(0u, k) : cell_empty(0u));
     }
     if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : 0u;
     if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; s_stats[threadIdx.x] = 0ull; }
@@ -488,18 +643,25 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         c.ra = A.ra; c.fc = fcp; c.cold = A.cold + (size_t)blockIdx.x * DE_V6_P; c.ctl = A.ctl; c.status = A.status;
         c.n_items = A.n_items; c.idle_limit = A.idle_limit;
         c.svc[0] = A.svc[0]; c.svc[1] = A.svc[1]; c.svc[2] = A.svc[2];
+        c.svc_area[0] = A.svc_area[0]; c.svc_area[1] = A.svc_area[1]; c.svc_area[2] = A.svc_area[2];
         c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.flat_min = A.flat_min;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];
     }
     __syncthreads();
+    if (threadIdx.x == 0u) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_START * DE_V6_CTL_STRIDE), (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
     W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (;;) {
         const int s = W.schedule();
         W.template mark<-1>();
-        if (s == Q_EXIT) { if (STATS && W.t_drain) W.stat(ST_DRAIN, __builtin_amdgcn_s_memrealtime() - W.t_drain); break; }
+        if (s == Q_EXIT) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (lane_id() == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(A.ctl + G_T_END * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STATS && W.t_drain) W.stat(ST_DRAIN, now - W.t_drain);
+            break;
+        }
         switch (s) {
         case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
         case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;

@@ -249,6 +249,12 @@ class EarthViewer:
             r.reset_framebuffer()
         return self._image
 
+    def close(self):
+        """Release the renderer.  A zero-copy image kept from frame(copy=False) is copied first: it lives in the renderer's staging buffer."""
+        if self._image is not None and getattr(self._image, "_owner", None) is not None:
+            self._image = np.array(self._image)
+        self.renderer.close()
+
     def save(self, path):
         """'p' screenshot (:244-250): writes the displayed image; `.npy` keeps the float (W, H, 3) array."""
         if self._image is None:

@@ -1,4 +1,4 @@
-"""Multi-GPU tile partition of one frame (no reference counterpart; BASELINE.json north_star).
+"""Multi-GPU partition of one frame (no reference counterpart; BASELINE.json north_star): tiles (default) or samples.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The image grid is cut into 8x8-pixel
 tiles (one wavefront each); tile (tx, ty) belongs to rank (tx + ty) % world — a diagonal interleave, so that every
@@ -11,6 +11,12 @@ Two ways to run the collective:
   * `reduce_hdr` — torch.distributed on a torch-owned HDR tensor (default; what bench.py times);
   * `LibraryComm` — the library's own RCCL communicator behind the C ABI (`de_comm_init` / `de_reduce`,
     include/digital_earth.h), for hosts without PyTorch; only the 128-byte unique id has to travel between ranks.
+
+The SAMPLE partition (`split="samples"`, SURVEY §8e's alternative for the 1024-spp progressive config; the reference's loop is one
+accumulate() per sample index, renderer.py:371-380): every rank renders the whole image for the sample indices = rank (mod world) —
+perfect balance, no per-tile launch tail.  Every pixel then has a partial sum on every rank and f32 addition is not associative, so the
+collective is `reduce_hdr_ordered`: gather on the root, add in rank order.  The assembled frame is bit-identical to those partial sums
+added that way on any machine; against the 1-rank frame it differs by re-association only (relative L2 <= 1e-6, tests).
 
 The functions take torch tensors on any device, which is how the world_size-2 gloo tests exercise them on CPU.
 """
@@ -65,6 +71,31 @@ def reduce_hdr(hdr, dst=0, group=None, out=None):
     return hdr
 
 
+def reduce_hdr_ordered(hdr, dst=0, group=None, out=None):
+    """The collective of a SAMPLE partition: the per-rank buffers (partial sums of every pixel) are gathered on `dst` and added in RANK
+    order — ((h0 + h1) + h2) + ... — so the result does not depend on how RCCL would have ordered a sum-reduce.  out=None: the root's
+    `hdr` becomes the assembled frame; out=tensor: out of place (progressive display: every rank keeps its running sums).
+    12 W H bytes per peer into the root: 25 MB x 7 over seven xGMI links at 1080p."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        if out is not None:
+            out.copy_(hdr)
+            return out
+        return hdr
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    staged = hdr.is_cuda and dist.get_backend(group) != "nccl"       # gloo: through host memory (several ranks on ONE GPU, CPU tests)
+    src = hdr.cpu() if staged else hdr
+    parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+    dist.gather(src, gather_list=parts, dst=dst, group=group)
+    if rank == dst:
+        acc = parts[0].clone()
+        for r in range(1, world):
+            acc += parts[r]
+        (out if out is not None else hdr).copy_(acc)
+    return out if out is not None else hdr
+
+
 class DistributedFrame:
     """Binds a Renderer to this process's rank: torch owns the HDR buffer (so RCCL can reduce it in place) and the
     renderer uses a torch stream as its context stream (so the collective is ordered after the launches, see `flush`).
@@ -72,11 +103,13 @@ class DistributedFrame:
     Lifetime: the Renderer is handed references to the tensor and the stream (`Renderer._bound`), so neither can be
     collected while the context still points at them; `close()` gives the context back its own buffer and stream."""
 
-    def __init__(self, renderer, rank, world, device_index, stream=None):
+    def __init__(self, renderer, rank, world, device_index, stream=None, split="tiles"):
         import torch
+        if split not in ("tiles", "samples"):
+            raise ValueError(split)
         self.torch = torch
         self.r = renderer
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.split = rank, world, split
         self.device = torch.device("cuda", device_index)
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         W, H = renderer.image_res
@@ -91,14 +124,19 @@ class DistributedFrame:
         renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
         renderer.set_stream(self.stream.cuda_stream)
         renderer._bound = (self.hdr, self.stream)
-        renderer.set_tile_partition(rank, world)
+        if split == "samples":
+            renderer.set_tile_partition(0, 1)
+            renderer.set_sample_partition(rank, world)
+        else:
+            renderer.set_sample_partition(0, 1)
+            renderer.set_tile_partition(rank, world)
 
     def _reduce(self, out=None):
         # what follows is torch's own work on this stream (the collective, or with one rank the copy into `out`): order it
         # after the launches — they run on the context's launch slots, not on this stream
         self.r.flush()
         self._ev[0].record(self.stream)
-        reduce_hdr(self.hdr, dst=0, out=out)
+        (reduce_hdr_ordered if self.split == "samples" else reduce_hdr)(self.hdr, dst=0, out=out)
         self._ev[1].record(self.stream)
         self._timed = True
 
@@ -169,18 +207,28 @@ class LibraryComm:
     tests/test_gpu_round2.py runs it with one rank, tests/test_a_multi_rank_gpu.py asserts RCCL's clean refusal of two ranks on
     one device)."""
 
-    def __init__(self, renderer, rank, world, exchange):
+    def __init__(self, renderer, rank, world, exchange, split="tiles"):
+        if split not in ("tiles", "samples"):
+            raise ValueError(split)
         self.r = renderer
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.split = rank, world, split
         uid = renderer.comm_unique_id() if rank == 0 else None
         uid = exchange(uid)
         renderer.comm_init(uid, rank, world)
-        renderer.set_tile_partition(rank, world)
+        if split == "samples":
+            renderer.set_tile_partition(0, 1)
+            renderer.set_sample_partition(rank, world)
+        else:
+            renderer.set_sample_partition(0, 1)
+            renderer.set_tile_partition(rank, world)
 
     def render_frame(self, spp, root=0):
         self.r.reset_framebuffer()
         self.r.accumulate(spp)
-        self.r.reduce(root)
+        if self.split == "samples":
+            self.r.reduce_ordered(root)
+        else:
+            self.r.reduce(root)
         if self.rank == root:
             self.r.render_to_image_device()
 
@@ -190,7 +238,10 @@ class LibraryComm:
         while done < spp:
             n = min(every, spp - done)
             self.r.accumulate(n)
-            self.r.reduce_progressive(root)
+            if self.split == "samples":
+                self.r.reduce_ordered(root, out_of_place=True)
+            else:
+                self.r.reduce_progressive(root)
             if self.rank == root:
                 self.r.render_to_image_device()
             done += n

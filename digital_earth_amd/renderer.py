@@ -52,6 +52,15 @@ class _VectorField:
         self._owner._push_params()
 
 
+class _StagingView(np.ndarray):
+    """fetch_image(copy=False): a read-only window on the library's pinned staging buffer.  Overwritten by the next fetch_* call of its
+    Renderer; holds a reference to that Renderer so that garbage collection cannot free the buffer under it."""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class Renderer:
     """GPU implementation of the reference `Renderer` (renderer.py:15-401).
 
@@ -116,8 +125,12 @@ class Renderer:
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
-        """de_destroy.  Fails (DigitalEarthError, DE_ERR_STATE) while another Renderer still borrows this one's maps."""
+        """de_destroy.  Fails (DigitalEarthError, DE_ERR_STATE) while another Renderer still borrows this one's maps, and (RuntimeError)
+        while a zero-copy image of fetch_image(copy=False) is still referenced: that array IS the context's pinned staging buffer."""
         if getattr(self, "_h", None):
+            ref = getattr(self, "_view_ref", None)
+            if ref is not None and ref() is not None:
+                raise RuntimeError("a fetch_image(copy=False) view of this Renderer is still referenced: drop it (or copy it) before close()")
             check(self._lib.de_destroy(self._h))
             self._h = ctypes.c_void_p()
             self._lender = None
@@ -339,6 +352,15 @@ class Renderer:
             raise ValueError("rank %d not in [0, %d)" % (rank, world))
         self.tile_rank, self.tile_world = int(rank), int(world)
 
+    def set_sample_partition(self, rank, world):
+        """Multi-GPU, the other split: this context renders, of the frame's sample indices, those = rank (mod world) of every
+        pixel it owns; accumulate(spp) still advances the frame's sample counter by spp.  The ranks' buffers are then partial sums of every
+        pixel: assemble them with reduce_ordered / parallel.reduce_hdr_ordered (rank-ordered additions), not with a plain sum-reduce."""
+        if not (0 <= rank < world):
+            raise ValueError("rank %d not in [0, %d)" % (rank, world))
+        check(self._lib.de_set_sample_partition(self._h, int(rank), int(world)))
+        self.sample_rank, self.sample_world = int(rank), int(world)
+
     # ------------------------------------------------------------------ frame loop, renderer.py:367-384
     def reset_framebuffer(self):
         self.current_spp = 0
@@ -360,8 +382,10 @@ class Renderer:
         if not copy:
             ptr = ctypes.POINTER(ctypes.c_float)()
             check(self._lib.de_fetch_image_view(self._h, ctypes.byref(ptr)))
-            view = np.ctypeslib.as_array(ptr, shape=(self.image_res[0], self.image_res[1], 3))
+            view = np.ctypeslib.as_array(ptr, shape=(self.image_res[0], self.image_res[1], 3)).view(_StagingView)
             view.flags.writeable = False
+            view._owner = self                      # the memory belongs to the context: the view keeps its Renderer alive ...
+            self._view_ref = weakref.ref(view)      # ... and close() refuses while the view is
             return view
         out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
         check(self._lib.de_fetch_image(self._h, out.ctypes.data))
@@ -407,6 +431,13 @@ class Renderer:
         name = {0: "ray marcher", 1: "per-lane loops", 2: "state machine", 5: "persistent stage scheduler", 6: "per-CU stage scheduler",
                 3: "pipeline x%d, %d rounds%s" % (pipes, depths, " + state machine" if depths < 25 else "")}.get(variant, "?")
         return dict(variant=variant, pipes=pipes, depths=depths, launches=launches, kernel=name)
+
+    def last_launch_phases(self):
+        """(launch_ms, drain_ms) of the last render_kernel_v6 launch, from the kernel's own clock: the drain is the time between the
+        first wave that found no work item left and the last wave's exit (include/digital_earth.h)."""
+        ms = (ctypes.c_float * 2)()
+        check(self._lib.de_last_launch_phases(self._h, ms))
+        return float(ms[0]), float(ms[1])
 
     def v5_stats(self, n=24):
         """Statistics block of the persistent stage scheduler (kernel variant 5 with DE_V5_STATS=1); include/digital_earth.h."""
@@ -467,6 +498,11 @@ class Renderer:
     def reduce_progressive(self, root=0, comm=None):
         """Out-of-place sum onto `root`: this rank keeps accumulating; the root displays the assembled frame (progressive mode)."""
         check(self._lib.de_reduce_progressive(self._h, ctypes.c_void_p(comm) if comm else None, int(root)))
+
+    def reduce_ordered(self, root=0, comm=None, out_of_place=False):
+        """Sample partition: gather the ranks' HDR buffers on `root` and add them in rank order (in place, or into the assembled buffer
+        the display reads: progressive mode)."""
+        check(self._lib.de_reduce_ordered(self._h, ctypes.c_void_p(comm) if comm else None, int(root), 1 if out_of_place else 0))
 
     def last_reduce_ms(self):
         ms = ctypes.c_float()

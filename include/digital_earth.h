@@ -193,6 +193,17 @@ int de_reduce(de_ctx* ctx, void* comm, int root);
  * becomes what de_render_to_image / de_fetch_image / de_fetch_hdr read until the next de_reset.  (An in-place reduce would add
  * the other ranks' running sums into the root's again at the next reduce.) */
 int de_reduce_progressive(de_ctx* ctx, void* comm, int root);
+/* SAMPLE partition (SURVEY §8e "alternative for cfg5", reference renderer.py:371-380: one accumulate() per sample index, here dealt round
+ * robin): after de_set_sample_partition(rank, world) a context renders, of the frame's sample indices covered by a de_accumulate call,
+ * those = rank (mod world) of EVERY pixel it owns (combine with tile_rank = 0, tile_world = 1); the frame's sample counter advances by the
+ * call's whole spp on every rank, and the RNG stream of a sample depends on (seed, pixel, sample index) only.  Every pixel then has a
+ * partial sum on every rank, so the order of the cross-rank additions is part of the result: de_reduce_ordered gathers the ranks' buffers
+ * on the root (ncclSend / ncclRecv, one group) and adds them in rank order — ((p0 + p1) + p2) + ... — in place, or into the assembled
+ * buffer the display reads when out_of_place != 0 (progressive display: every rank keeps its running sums).  The assembled frame equals
+ * the same partial sums added in the same order by any other means bit for bit; against the one-rank frame (one running sum in sample
+ * order) it differs by f32 re-association: relative L2 <= 1e-6 (tests).  Perfect balance, no per-tile tail; 12 W H (world - 1) bytes into the root. */
+int de_set_sample_partition(de_ctx* ctx, int rank, int world);
+int de_reduce_ordered(de_ctx* ctx, void* comm, int root, int out_of_place);
 /* Duration of the last de_reduce / de_reduce_progressive on the context stream (HIP events, ms). */
 int de_last_reduce_ms(de_ctx* ctx, float* ms);
 /* Display transform source: a device buffer [H][W][3] f32 to read instead of the accumulation buffer (NULL = back to it) — for
@@ -259,6 +270,9 @@ int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
  * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
  * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [22] wave-time between the end of the work items and the wave's exit, [32..38] wave-trips of the loop
  * stages / passes of the straight-line stages, [40..46] the busy lanes summed over them.  Profiling aid. */
+/* Phases of the last render_kernel_v6 launch of the last de_accumulate call (the kernel's own 100 MHz clock): ms2[0] = first workgroup start to
+ * last wave exit, ms2[1] = the drain, from the first wave that found no work item left to the last wave's exit.  Waits for that launch. */
+int de_last_launch_phases(de_ctx* ctx, float* ms2);
 int de_debug_v6_stats(de_ctx* ctx, uint64_t* out, int n);
 int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 

@@ -67,6 +67,7 @@ def lib():
         L.deo_fetch_image.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.deo_fetch_hdr.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.deo_set_hdr.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.deo_set_sample_partition.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.deo_current_spp.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         L.deo_get_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeCounters)]
         L.deo_eval.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
@@ -149,6 +150,10 @@ class Oracle:
 
     def accumulate(self, spp=1, seed=0, tile_rank=0, tile_world=1):
         _check(lib().deo_accumulate(self._h, spp, seed, tile_rank, tile_world))
+
+    def set_sample_partition(self, rank, world):
+        """Of the frame's sample indices this oracle renders those = rank (mod world); accumulate(spp) still advances the index by spp."""
+        _check(lib().deo_set_sample_partition(self._h, rank, world))
 
     def debug_samples(self, seed, sample_index):
         out = np.zeros((self.H, self.W, 4), dtype=np.float32)

@@ -35,3 +35,26 @@ def test_render_kernel_v2_resource_budget(tmp_path):
         assert scratch <= 32 and spills <= 8, (name, scratch, spills)
         assert vgprs <= 96 and occupancy >= 5, (name, vgprs, occupancy)
         assert int(lds) * 20 <= 160 * 1024, (name, lds)
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+def test_render_kernel_v6_budget_and_hot_loops(tmp_path):
+    """render_kernel_v6 at its geometry (80 VGPRs = six waves per SIMD, 80 KB of LDS = two workgroups per CU) and, what the kernel's resource
+    line does not show, no scratch access inside any stage function besides the callee-saved registers at its entry and exit: at 80 VGPRs the
+    allocator is one live value away from reloading a map's base pointer inside a tracking loop (round 5: +5 % frame time)."""
+    import importlib.util
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    asm = str(tmp_path / "de.s")
+    out = subprocess.run([HIPCC] + flags + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(build.CSRC, "de_api.hip"), "-o", asm],
+                         cwd=build.CSRC, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"Function Name: (_Z9v6_kernelILb0ELb0EE\S*)(.*?)LDS Size \[bytes/block\]: (\d+)", out.stderr, re.S)
+    assert m, "v6_kernel<false, false> not found"
+    body, lds = m.group(2), int(m.group(3))
+    assert int(re.search(r"VGPRs: (\d+)", body).group(1)) <= 80 and int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", body).group(1)) >= 6
+    assert lds * 2 <= 160 * 1024
+    spec = importlib.util.spec_from_file_location("v6_hot_loops", os.path.join(os.path.dirname(build.CSRC), "..", "tools", "v6_hot_loops.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for stage, r in mod.hot_loops(asm).items():
+        assert r["mid_scratch"] == 0, (stage, r)

@@ -1,0 +1,162 @@
+"""Round 5: the sample partition (SURVEY §8e's alternative split; reference renderer.py:371-380 dealt round robin) against the oracle,
+the rank-ordered assembly, the ring protocol of render_kernel_v6 on pools small enough that every cell is reused thousands of times,
+the launch's drain clock, the zero-copy image's lifetime."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import make_oracle, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def Renderer():
+    from digital_earth_amd.renderer import Renderer as R
+    return R
+
+
+def _pair(Renderer, lut_arrays, W=128, H=64, fov=0.42, seed=21):
+    r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(2048, 1024), seed=seed)
+    r.set_fov(fov)
+    r.copy_textures()
+    o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
+    return r, o
+
+
+@pytest.mark.timeout(900)
+def test_sample_partition_against_the_oracle(Renderer, lut_arrays):
+    """Rank k of a 3-way sample partition renders sample indices k, k + 3, ... of every pixel; the frame's counter advances by the whole
+    call on every rank; calls of 2 + 5 + 1 samples split the same indices as one call of 8.  Each rank's buffer equals the oracle's for
+    the same partition bit for bit (8192 paths per sample index: render_kernel_v6; the last rank also on the state machine)."""
+    WORLD, SEED = 3, 21
+    parts = []
+    for rank in range(WORLD):
+        r, o = _pair(Renderer, lut_arrays)
+        r.set_sample_partition(rank, WORLD)
+        for n in (2, 5, 1):
+            r.accumulate(n)
+        assert r.current_spp == 8
+        o.set_sample_partition(rank, WORLD)
+        o.accumulate(8, SEED)
+        g, c = r.fetch_hdr(), o.fetch_hdr()
+        assert (g.view(np.uint32) == c.view(np.uint32)).all()
+        if rank == WORLD - 1:
+            r.set_kernel_variant(2)
+            r.reset_framebuffer()
+            r.accumulate(8)
+            assert (r.fetch_hdr().view(np.uint32) == c.view(np.uint32)).all()
+        parts.append(g)
+        r.close()
+    # the assembled frame: partial sums in rank order; against one running sum in sample order it is re-association only
+    assembled = (parts[0] + parts[1]) + parts[2]
+    r, o = _pair(Renderer, lut_arrays)
+    r.accumulate(8)
+    solo = r.fetch_hdr()
+    assert rel_l2(assembled, solo) <= 1e-6
+    assert np.abs(assembled - solo).max() <= 1e-6 * np.abs(solo).max()      # per element: a few ulps of the pixel's largest partial sum (RGB channels cancel)
+    r.close()
+
+
+@pytest.mark.timeout(900)
+def test_sample_partition_with_an_empty_share(Renderer, lut_arrays):
+    """A call that holds no sample index of this rank launches nothing and still advances the frame's counter."""
+    r, o = _pair(Renderer, lut_arrays)
+    r.set_sample_partition(3, 4)
+    r.accumulate(2)                       # indices 0, 1: none of them = 3 (mod 4)
+    assert r.current_spp == 2 and not r.fetch_hdr().any()
+    r.accumulate(3)                       # indices 2, 3, 4: index 3
+    o.set_sample_partition(3, 4)
+    o.accumulate(5, 21)
+    assert (r.fetch_hdr().view(np.uint32) == o.fetch_hdr().view(np.uint32)).all()
+    r.close()
+
+
+def _ordered_reference(n):
+    rng = np.random.default_rng(5)
+    return [rng.standard_normal(n).astype(np.float32) * np.float32(10.0 ** rng.integers(-3, 4)) for _ in range(4)]
+
+
+@pytest.mark.timeout(600)
+def test_library_ordered_reduce_with_one_rank(Renderer):
+    """de_reduce_ordered through a 1-rank communicator of the library (RCCL refuses two ranks on one device): the root's own buffer is the
+    only part, in place and out of place."""
+    r = Renderer((64, 32), (0, 1, 0), texture_source="synthetic", texture_size=(512, 256))
+    r.copy_textures()
+    r.comm_init(r.comm_unique_id(), 0, 1)
+    r.set_sample_partition(0, 1)
+    r.accumulate(2)
+    before = r.fetch_hdr()
+    r.reduce_ordered(0)
+    assert (r.fetch_hdr().view(np.uint32) == before.view(np.uint32)).all()
+    r.reduce_ordered(0, out_of_place=True)
+    assert (r.fetch_hdr().view(np.uint32) == before.view(np.uint32)).all()      # the display source is the assembled buffer now
+    assert r.last_reduce_ms() >= 0.0
+    r.comm_destroy()
+    r.close()
+
+
+VARIANTS = [("v6_p64", "-DDE_V6_P=64u -DDE_V6_CAP=65u"), ("v6_p128", "-DDE_V6_P=128u -DDE_V6_CAP=129u"), ("v6_cap_p1", "-DDE_V6_CAP=1121u")]
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from digital_earth_amd.renderer import Renderer
+from digital_earth_amd.earth_viewer import load_config
+out = {}
+for k, (W, H, spp, preset, heavy) in enumerate(((256, 128, 6, None, False), (192, 96, 5, "config - sunset hurricane.txt", True), (128, 64, 7, "config - florida.txt", False))):
+    r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(2048, 1024), cloud_heavy=heavy, seed=3)
+    if preset: load_config(preset).apply(r)
+    r.set_kernel_variant(6)
+    for rep in range(int(os.environ.get("DE_TEST_REPS", "1"))):
+        r.reset_framebuffer(); r.accumulate(spp)
+        out["f%%d_%%d" %% (k, rep)] = r.fetch_hdr()
+    r.close()
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.timeout(3000)
+def test_ring_protocol_on_small_pools(tmp_path):
+    """VERDICT r4 weak #7 / ADVICE: the rings of render_kernel_v6 at DE_V6_CAP = DE_V6_P + 1 (no slack between what can be queued and the
+    ring's size) and with pools of 64 and 128 slots per workgroup (a frame recycles every slot and every ring cell thousands of times; 12
+    waves compete for one or two wave-loads of slots, so claims, takes and appends interleave as tightly as they can).  The variant
+    libraries are built by __graft_entry__.build() (tools/ab_build.sh: the same sources with -D flags); every frame must equal the
+    shipped geometry's bit for bit — a lost, duplicated or stale slot number is a wrong pixel or the abort word, never silent."""
+    env = dict(os.environ)
+    code = _CHILD % {"root": ROOT}
+    ref_path = str(tmp_path / "ref.npz")
+    subprocess.run([sys.executable, "-c", code, ref_path], check=True, env=env, timeout=900)
+    ref = np.load(ref_path)
+    for name, _flags in VARIANTS:
+        lib = os.path.join(ROOT, "build", "ab", name + ".so")
+        assert os.path.exists(lib), "variant library %s missing: run __graft_entry__.build()" % lib
+        env2 = dict(env, DE_LIB_PATH=lib, DE_TEST_REPS="3")
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env2, timeout=1800)
+        got = np.load(path)
+        for key in got.files:
+            want = ref[key.rsplit("_", 1)[0] + "_0"]
+            assert (got[key].view(np.uint32) == want.view(np.uint32)).all(), "%s %s" % (name, key)
+
+
+@pytest.mark.timeout(600)
+def test_launch_phases_and_zero_copy_image_lifetime(Renderer):
+    r = Renderer((256, 128), (0, 1, 0), texture_source="synthetic", texture_size=(1024, 512))
+    r.copy_textures()
+    r.accumulate(4)
+    launch_ms, drain_ms = r.last_launch_phases()
+    assert r.last_call_info()["variant"] == 6
+    assert 0.0 < drain_ms <= launch_ms < 1e4
+    view = r.fetch_image(copy=False)
+    assert not view.flags.writeable and view._owner is r
+    with pytest.raises(RuntimeError):
+        r.close()                         # the view IS the context's staging buffer
+    keep = np.array(view)
+    del view
+    r.close()
+    assert keep.max() <= 1.0

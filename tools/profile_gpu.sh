@@ -10,18 +10,18 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export DE_BIG_SLOTS=1    # one launch at a time: with several in flight the small kernels of one frame queue behind the persistent waves of the next and their durations show that wait
 cd /tmp
-BENCH="python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --sync-frames $*"   # one frame at a time: with two in flight the small kernels of one frame queue behind the persistent waves of the other and their durations show that wait
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
+BENCH=(python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames-in-flight 1 --sync-frames "$@")   # one frame at a time: with two in flight the small kernels of one frame queue behind the persistent waves of the other and their durations show that wait
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- "${BENCH[@]}" > $OUT/stats.log 2>&1
 # SQ pass 1: issue / occupancy
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU \
-  --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_sq1 -o pmc -- $BENCH > $OUT/pmc_sq1.log 2>&1
+  --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_sq1 -o pmc -- "${BENCH[@]}" > $OUT/pmc_sq1.log 2>&1
 # SQ pass 2: stalls
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE \
-  --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1
+  --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_sq2 -o pmc -- "${BENCH[@]}" > $OUT/pmc_sq2.log 2>&1
 # TCC passes: HBM traffic (FETCH_SIZE costs 3 of 4 TCC slots, WRITE_SIZE 2: separate passes)
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_l2 -o pmc -- $BENCH > $OUT/pmc_l2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_fetch -o pmc -- "${BENCH[@]}" > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_write -o pmc -- "${BENCH[@]}" > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-include-regex "render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel" --output-format csv -d $OUT/pmc_l2 -o pmc -- "${BENCH[@]}" > $OUT/pmc_l2.log 2>&1
 # keep only the small files
 find $OUT -name "*.csv" -size +24M -delete
 ls -R $OUT | head -50
