@@ -39,6 +39,7 @@ DE_FLAG_FIXED_WAVELENGTH = 1 << 0
 DE_FLAG_CLAMP_SAMPLER = 1 << 1
 DE_FLAG_RAY_MARCHER = 1 << 2
 DE_FLAG_AGX = 1 << 3
+DE_FLAG_FAST_MATH = 1 << 5
 
 # name -> (restype, argtypes): every symbol include/digital_earth.h declares
 _P = ctypes.c_void_p
@@ -84,13 +85,14 @@ SYMBOLS = {
     "de_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(DeCounters)]),
     "de_enable_counters": (ctypes.c_int, [_P, ctypes.c_int]),
     "de_set_kernel_variant": (ctypes.c_int, [_P, ctypes.c_int]),
+    "de_get_tuning": (ctypes.c_int, [_P, _P]),
+    "de_set_tuning": (ctypes.c_int, [_P, _P]),
     "de_debug_samples": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_int, _P]),
     "de_debug_sched_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_set_memory_budget": (ctypes.c_int, [_P, ctypes.c_uint64]),
     "de_get_memory_use": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "de_last_call_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "de_last_launch_phases": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
-    "de_debug_v5_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_v6_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),
     "de_last_error": (ctypes.c_char_p, []),
@@ -98,8 +100,58 @@ SYMBOLS = {
     "de_arithmetic_contract": (ctypes.c_int, []),
 }
 
+# entry points of the legacy library only (include/digital_earth_legacy.h): bound when present
+LEGACY_SYMBOLS = {
+    "de_debug_v5_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
+}
+
+
+class DeTuning(ctypes.Structure):
+    """de_tuning of include/digital_earth.h"""
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("kernel_variant", ctypes.c_int32), ("launch_slots", ctypes.c_int32), ("big_launch_slots", ctypes.c_int32),
+                ("v6_min_paths", ctypes.c_uint64), ("v6_service_area", ctypes.c_int32 * 3), ("v6_service_lanes", ctypes.c_int32 * 3),
+                ("v6_yield_max", ctypes.c_int32), ("v6_elsewhere_min", ctypes.c_int32), ("v6_retry", ctypes.c_int32), ("v6_enter_min", ctypes.c_int32),
+                ("v6_flat_min", ctypes.c_int32), ("v6_flat_again", ctypes.c_int32), ("v6_bands", ctypes.c_int32), ("v6_stats", ctypes.c_int32),
+                ("v2_pend", ctypes.c_int32), ("v2_heavy", ctypes.c_int32), ("v2_b", ctypes.c_int32), ("v2_gas", ctypes.c_int32), ("v2_chunk", ctypes.c_int32),
+                ("v2_waves_per_cu", ctypes.c_int32), ("v2_max_spp", ctypes.c_int32), ("trace", ctypes.c_int32)]
+
+
+# Experiment overrides: the LIBRARY reads no environment variable for its tuning (de_set_tuning); this layer does, once per context, for the
+# tools and tests that sweep knobs from the shell.  environment name -> (de_tuning field, index or None)
+ENV_TUNING = {
+    "DE_KERNEL": ("kernel_variant", None), "DE_SLOTS": ("launch_slots", None), "DE_BIG_SLOTS": ("big_launch_slots", None),
+    "DE_AUTO_V6_MIN_ITEMS": ("v6_min_paths", None), "DE_V6_STATS": ("v6_stats", None), "DE_AUTO_TRACE": ("trace", None),
+    "DE_V6_AREA_ST": ("v6_service_area", 0), "DE_V6_AREA_GAS": ("v6_service_area", 1), "DE_V6_AREA_CLOUD": ("v6_service_area", 2),
+    "DE_V6_SVC_ST": ("v6_service_lanes", 0), "DE_V6_SVC_GAS": ("v6_service_lanes", 1), "DE_V6_SVC_CLOUD": ("v6_service_lanes", 2),
+    "DE_V6_YIELD": ("v6_yield_max", None), "DE_V6_ELSEWHERE": ("v6_elsewhere_min", None), "DE_V6_RETRY": ("v6_retry", None),
+    "DE_V6_ENTER_MIN": ("v6_enter_min", None), "DE_V6_FLAT_MIN": ("v6_flat_min", None), "DE_V6_FLAT_AGAIN": ("v6_flat_again", None), "DE_V6_BANDS": ("v6_bands", None),
+    "DE_V2_THR": ("v2_pend", None), "DE_V2_A": ("v2_heavy", None), "DE_V2_B": ("v2_b", None), "DE_V2_G": ("v2_gas", None),
+    "DE_V2_CHUNK": ("v2_chunk", None), "DE_V2_WPC": ("v2_waves_per_cu", None), "DE_V2_MAX_SPP": ("v2_max_spp", None),
+}
+
+
+def apply_env_tuning(handle):
+    """Read the experiment overrides above from the environment and hand them to the context in one de_set_tuning call (nothing is set: no call)."""
+    found = {k: os.environ[k] for k in ENV_TUNING if os.environ.get(k, "") != ""}
+    if not found:
+        return
+    L = load()
+    t = DeTuning()
+    check(L.de_get_tuning(handle, ctypes.byref(t)))
+    for name, text in found.items():
+        field, i = ENV_TUNING[name]
+        value = 1 if (name == "DE_AUTO_TRACE" and not text.lstrip("-").isdigit()) else int(text)
+        if i is None:
+            setattr(t, field, value)
+        else:
+            getattr(t, field)[i] = value
+    if "DE_SLOTS" in found and "DE_BIG_SLOTS" not in found:
+        t.big_launch_slots = min(t.big_launch_slots, t.launch_slots)
+    check(L.de_set_tuning(handle, ctypes.byref(t)))
+
+
 _lib = None
-ABI_VERSION = 4   # DE_ABI_VERSION of include/digital_earth.h
+ABI_VERSION = 5   # DE_ABI_VERSION of include/digital_earth.h
 
 
 class NativeLibraryError(RuntimeError):
@@ -131,6 +183,11 @@ def load():
             raise NativeLibraryError("%s does not export %s" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in LEGACY_SYMBOLS.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
     if L.de_abi_version() != ABI_VERSION:
         raise NativeLibraryError("%s has ABI version %d, this binding expects %d: rebuild it" % (LIB_PATH, L.de_abi_version(), ABI_VERSION))
     _lib = L

@@ -5,9 +5,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libdigitalearth_hip.so")
-SOURCES = ["de_api.hip"]   # single translation unit: includes render_kernel.hip and aux_kernels.hip
-DEPS = ["de_api.hip", "render_kernel.hip", "render_kernel_v2.hip", "render_kernel_v3.hip", "render_kernel_v5.hip", "render_kernel_v6.hip", "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h",
-        os.path.join("..", "..", "include", "digital_earth.h")]
+# The same sources with -DDE_LEGACY_VARIANTS: the product plus the kernel families it no longer runs (per-lane loops, the wavefront pipeline and its
+# launch policy, the HBM-queue scheduler) — three more statements of path_tracer for the cross-check tests (tests/legacy/, loaded through DE_LIB_PATH).
+OUT_LEGACY = os.path.join(_HERE, "libdigitalearth_hip_legacy.so")
+SOURCES = ["de_api.hip", "de_fast.hip"]   # de_fast.hip: render_kernel_v6 once more, on the hardware transcendentals (DE_FLAG_FAST_MATH).  de_api.hip is one translation unit: de_api.hip -> de_rccl.h -> de_launch.h -> de_host_consts.h -> de_context.h -> the kernels
+DEPS = ["de_api.hip", "de_fast.hip", "de_rccl.h", "de_launch.h", "de_host_consts.h", "de_context.h", "render_kernel.hip", "render_kernel_v2.hip", "de_stages.h", "render_kernel_v6.hip",
+        "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h", os.path.join("..", "..", "include", "digital_earth.h")]
+DEPS_LEGACY = DEPS + [os.path.join("legacy", f) for f in ("render_kernel_v3.hip", "render_kernel_v5.hip", "de_launch_legacy.h", "de_ctx_legacy_members.inc")]
 # -ffp-contract=off is part of the arithmetic contract (de_math.h): fused operations only where written.
 # -fno-slp-vectorize: the SLP vectoriser packs pairs of scalar f32 operations into v_pk_* instructions; on gfx950 the
 # moves that build the register pairs cost more than the packing saves in this kernel (measured: 358 -> 334 ms per frame).
@@ -32,6 +36,17 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     return OUT
+
+
+def build_legacy(force=False, verbose=False):
+    if not force and os.path.exists(OUT_LEGACY) and all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(OUT_LEGACY) for d in DEPS_LEGACY):
+        return OUT_LEGACY
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-DDE_LEGACY_VARIANTS"] + os.environ.get("DE_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT_LEGACY]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT_LEGACY
 
 
 # Geometry variants of render_kernel_v6 for tests/test_gpu_round5.py::test_ring_protocol_on_small_pools: the same sources with -D flags

@@ -26,6 +26,71 @@ DE_DEV float de_min(float a, float b) { return (b < a) ? b : a; }
 DE_DEV float de_clamp(float x, float lo, float hi) { return de_min(de_max(x, lo), hi); }
 DE_DEV float de_saturate(float x) { return de_clamp(x, 0.0f, 1.0f); }
 
+#ifdef DE_FAST_MATH
+// ---------------------------------------------------------------------------------------------------- DE_FLAG_FAST_MATH (round 5, opt-in)
+// The same functions on the hardware's transcendental units — v_exp_f32 / v_log_f32 / v_sin_f32 / v_cos_f32 / v_sqrt_f32 / v_rcp_f32 / v_rsq_f32
+// (about 1 ulp each, unspecified roundings) — and shorter polynomials for atan2 / asin: what the arithmetic contract costs, priced
+// (profiles/r5_fast_math.md).  NOT bit-reproducible against the CPU oracle: a sample whose `rand < p` test lands on the other side follows a
+// different path from there on.  Compiled into a second instantiation of render_kernel_v6 only (de_fast.hip); the default kernels never see this.
+DE_DEV float de_div_rc_ng(float x, float c, float rc) { (void)c; return x * rc; }
+#define DE_DIVC_NG(x, c) ((x) * (1.0f / (c)))
+DE_DEV float de_sqrt_nr(float x) { return __builtin_amdgcn_sqrtf(x); }
+DE_DEV float de_rcp_nr(float b) { return __builtin_amdgcn_rcpf(b); }
+#define DE_PI 0x1.921fb6p+1f
+#define DE_PIO2 0x1.921fb6p+0f
+#define DE_LOG2E 0x1.715476p+0f
+#define DE_LN2 0x1.62e430p-1f
+#define DE_INF __builtin_inff()
+#define DE_INV_PI ((float)(1.0 / 3.14159265358979323846))
+#define DE_INV_2PI ((float)(0.5 / 3.14159265358979323846))
+#define DE_INV_255 ((float)(1.0 / 255.0))
+DE_DEV float de_exp(float x) { return __builtin_amdgcn_exp2f(x * DE_LOG2E); }
+DE_DEV float de_exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * DE_LOG2E); }
+DE_DEV float de_log(float x) { return __builtin_amdgcn_logf(x) * DE_LN2; }
+DE_DEV float de_log_unit(float x) { return __builtin_amdgcn_logf(x) * DE_LN2; }      // log2(0) = -inf: the free flight of a zero draw stays +inf
+DE_DEV void de_sincos(float x, float* s_out, float* c_out) {
+    const float r = x * DE_INV_2PI;                       // v_sin_f32 / v_cos_f32 take revolutions
+    *s_out = __builtin_amdgcn_sinf(r); *c_out = __builtin_amdgcn_cosf(r);
+}
+DE_DEV float de_sin(float x) { return __builtin_amdgcn_sinf(x * DE_INV_2PI); }
+DE_DEV float de_cos(float x) { return __builtin_amdgcn_cosf(x * DE_INV_2PI); }
+// atan2: four coefficients (1.7e-5 rad: 0.06 texel of a 21 600-wide map); asin: the contract's four with the hardware sqrt
+DE_DEV float de_atan2(float y, float x) {
+    float ax = de_abs(x), ay = de_abs(y);
+    bool swap = ay > ax;
+    float mx = swap ? ay : ax, mn = swap ? ax : ay;
+    float a = mn * __builtin_amdgcn_rcpf(mx);
+    float s = a * a;
+    float p = 0x1.79d11ep-6f;                             // four coefficients fitted on [0, 1] (odd polynomial a + a s p(s)): 1.7e-5 rad
+    p = de_fma(p, s, -0x1.727c04p-4f);
+    p = de_fma(p, s, 0x1.79d652p-3f);
+    p = de_fma(p, s, -0x1.53a54cp-2f);
+    float r = de_fma(a * s, p, a);
+    if (swap) r = DE_PIO2 - r;
+    if (x < 0.0f) r = DE_PI - r;
+    if (y < 0.0f) r = -r;
+    return (mx == 0.0f) ? 0.0f : r;
+}
+DE_DEV float de_asin(float x) {
+    float ax = de_abs(x);
+    if (ax > 1.0f) ax = 1.0f;
+    bool big = ax > 0.5f;
+    float s = big ? (1.0f - ax) * 0.5f : ax * ax;
+    float t = big ? __builtin_amdgcn_sqrtf(s) : ax;
+    float p = 0x1.a7813ap-5f;
+    p = de_fma(p, s, 0x1.409a72p-5f);
+    p = de_fma(p, s, 0x1.35737ap-4f);
+    p = de_fma(p, s, 0x1.554bf8p-3f);
+    float r = de_fma(t * s, p, t);
+    if (big) r = de_fma(-2.0f, r, DE_PIO2);
+    return (x < 0.0f) ? -r : r;
+}
+DE_DEV float de_pow(float a, float b) {
+    if (b == 0.0f) return 1.0f;
+    if (b == 1.0f) return a;
+    return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(a));
+}
+#else
 // x / c in 3 operations instead of the ~12 of an IEEE divide, for a LITERAL divisor c with rc = RN(1/c) (the density
 // profiles: 49, 532307548.4168, 1.225, 8136.646).  That q below IS the correctly rounded x / c is a property of the divisor:
 // tools/verify_exact_div.c checks it exhaustively (all 2^23 significands) for every literal used, and
@@ -242,3 +307,5 @@ DE_DEV float de_pow(float a, float b) {
     if (b == 1.0f) return a;
     return de_exp(b * de_log(a));
 }
+
+#endif  // DE_FAST_MATH

@@ -20,7 +20,7 @@
 // atomics.  No fences, no spinning on data: the only waits are on a ring cell between its producer's ticket and its store (a few
 // hundred ns), and on the free-chunk ring when the pool is exhausted (sized so that it is not).  Every wait is bounded: a wave that
 // waits too long raises the abort word, every wave leaves, and the host reports DE_ERR_HIP instead of a hung GPU.
-#include "de_kernels.h"
+#include "../de_stages.h"
 
 namespace ps {
 
@@ -644,12 +644,7 @@ __global__ void v5_init_kernel(uint32_t* ctl, uint32_t* free_ring, uint32_t pool
     if (i == 0u) *dst = a;
 }
 
-// a pointer the optimiser knows nothing about: loads through it are neither hoisted above this point nor merged with earlier ones
-template <typename T> DE_DEV const T* v5_opaque(const T* p) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
-    asm volatile("" : "+s"(lo), "+s"(hi));
-    return reinterpret_cast<const T*>((uintptr_t)lo | ((uintptr_t)hi << 32));
-}
+template <typename T> DE_DEV const T* v5_opaque(const T* p) { return wf::opaque_ptr(p); }
 
 template <bool CLAMP, bool STATS, bool LOCAL>
 __global__ void __launch_bounds__(64, DE_V5_MIN_WAVES) v5_kernel(ps::Args A, const FrameConsts* fcp) {

@@ -17,6 +17,7 @@
 //
 // Results are IDENTICAL to render_kernel.hip and to the CPU oracle: each lane executes the same arithmetic in the
 // same order on its own RNG stream; only the interleaving between lanes changes.
+#pragma once
 #include "de_kernels.h"
 
 namespace v2 {

@@ -87,6 +87,7 @@ class Renderer:
         self.tile_rank, self.tile_world = 0, 1
         self._h = ctypes.c_void_p()
         check(self._lib.de_create(int(device), self.image_res[0], self.image_res[1], ctypes.byref(self._h)))
+        _native.apply_env_tuning(self._h)      # experiment overrides (DE_KERNEL, DE_V6_* ...): read HERE, not in the library
         self._params = DeParams()
         check(self._lib.de_get_params(self._h, ctypes.byref(self._params)))   # reference defaults, renderer.py:20-22,49-58
 
@@ -342,6 +343,12 @@ class Renderer:
             raise ValueError(name)
         self.set_flag(_native.DE_FLAG_AGX, name == "agx")
 
+    def set_fast_math(self, on=True):
+        """OPT-IN (DE_FLAG_FAST_MATH): path_tracer on the hardware's transcendental units instead of the arithmetic contract's fixed sequences.
+        Faster (profiles/r5_fast_math.md) and no longer bit-reproducible against the CPU oracle: a sample whose collision test lands on the other
+        side follows a different path, so images agree with the contract's statistically, not sample by sample."""
+        self.set_flag(_native.DE_FLAG_FAST_MATH, bool(on))
+
     def set_topo_res_override(self, res):
         self._params.topo_res_override = int(res)
         self._push_params()
@@ -439,8 +446,19 @@ class Renderer:
         check(self._lib.de_last_launch_phases(self._h, ms))
         return float(ms[0]), float(ms[1])
 
+    def tuning(self):
+        """The context's de_tuning (include/digital_earth.h) as a ctypes struct; change fields and pass it to set_tuning."""
+        t = _native.DeTuning()
+        check(self._lib.de_get_tuning(self._h, ctypes.byref(t)))
+        return t
+
+    def set_tuning(self, t):
+        check(self._lib.de_set_tuning(self._h, ctypes.byref(t)))
+
     def v5_stats(self, n=24):
-        """Statistics block of the persistent stage scheduler (kernel variant 5 with DE_V5_STATS=1); include/digital_earth.h."""
+        """Statistics block of the persistent stage scheduler (legacy library, kernel variant 5 with DE_V5_STATS=1); include/digital_earth_legacy.h."""
+        if not hasattr(self._lib, "de_debug_v5_stats"):
+            raise RuntimeError("de_debug_v5_stats lives in the legacy library (DE_LIB_PATH=.../libdigitalearth_hip_legacy.so)")
         out = (ctypes.c_uint64 * n)()
         check(self._lib.de_debug_v5_stats(self._h, out, n))
         return [int(x) for x in out]

@@ -26,8 +26,10 @@ extern "C" {
 /* 1: round 1.  2: round 2 (contract-2 arithmetic, de_share_textures / de_trim_textures / de_comm_* added, DE_FLAG_NO_FAST_DIVISION
  * retired) — shipped still reporting 1.  3: launch slots (de_flush), de_use_own_stream, de_set_stream(NULL) = the null stream,
  * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_fetch_image_view, de_debug_v5_stats, de_debug_v6_stats,
- * kernel variants 5 and 6. */
-#define DE_ABI_VERSION 4
+ * kernel variants 5 and 6.  5 (round 5): de_set_tuning / de_get_tuning replace every environment variable the library used to read for its
+ * tuning; de_set_sample_partition, de_reduce_ordered, de_last_launch_phases added; kernel variants 1, 3 and 5 and de_debug_v5_stats moved to the
+ * legacy library (digital_earth_legacy.h); an abort of a persistent launch is sticky until de_reset. */
+#define DE_ABI_VERSION 5
 /* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
 #define DE_ARITHMETIC_CONTRACT 2
 
@@ -58,7 +60,11 @@ enum {
     DE_FLAG_CLAMP_SAMPLER = 1u << 1,    /* CLAMP_TO_EDGE instead of REPEAT texture addressing */
     DE_FLAG_RAY_MARCHER = 1u << 2,      /* integrate with ray_marcher (pathtracer.py:544-685) instead of path_tracer */
     DE_FLAG_AGX = 1u << 3,              /* display with srgb_transfer(AgX(linear)) — the alternative at renderer.py:356 (lib/AgX.py) — instead of OpenDRT + CRF + gamma */
-    DE_FLAG_RESERVED_4 = 1u << 4        /* was a round-1 test hook (IEEE-divide fallback of the tracking loops); ignored since contract 2 */
+    DE_FLAG_RESERVED_4 = 1u << 4,       /* was a round-1 test hook (IEEE-divide fallback of the tracking loops); ignored since contract 2 */
+    DE_FLAG_FAST_MATH = 1u << 5         /* OPT-IN, not bit-reproducible: path_tracer on the hardware's exp / log / sin / cos / sqrt / rcp units and shorter atan2 / asin
+                                           polynomials instead of the arithmetic contract's fixed sequences (render_kernel_v6 only; counting and trace launches and the ray
+                                           marcher keep the contract).  A sample whose collision test lands on the other side follows a different path: the image agrees with
+                                           the contract's statistically, not sample by sample (profiles/r5_fast_math.md: time, flip rate and L2 per camera). */
 };
 
 /* Scalar state of the reference Renderer (renderer.py:18-58), set through its set_* kernels (:224-266). */
@@ -235,6 +241,26 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *   6            per-CU stage scheduler: ONE launch, two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
  * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..6 selects the variant at de_create. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
+
+/* Tuning of the product's kernels as one plain struct — the library reads NO environment variable for any of this (the only ones it
+ * reads are DE_RCCL_PATH / DE_RCCL_STRICT, where to find librccl.so); a host that wants experiment overrides reads its own environment
+ * (digital_earth_amd/_native.py does) and calls de_set_tuning.  Usage: de_get_tuning (fills struct_bytes and the current values), change
+ * fields, de_set_tuning.  None of the values moves a bit of the image: they move time. */
+typedef struct de_tuning {
+    uint32_t struct_bytes;            /* sizeof(de_tuning) of the library that filled it */
+    int32_t kernel_variant;           /* as de_set_kernel_variant: 4 automatic (default), 2 state machine, 6 per-CU stage scheduler */
+    int32_t launch_slots, big_launch_slots;   /* as de_set_launch_slots */
+    uint64_t v6_min_paths;            /* automatic variant: calls of at least this many paths run render_kernel_v6 (default 4096) */
+    int32_t v6_service_area[3];       /* sphere trace / gas / cloud: idle lane-trips since its last service at which a loop stage services; 0 = use v6_service_lanes */
+    int32_t v6_service_lanes[3];      /* ... idle lanes at which it does (the rule of round 4) */
+    int32_t v6_yield_max, v6_elsewhere_min, v6_retry, v6_enter_min, v6_flat_min, v6_flat_again;   /* render_kernel_v6.hip: bs::Args */
+    int32_t v6_bands;                 /* 8: one work counter per XCD, each over its own band of the launch's tiles (default); 1: one counter */
+    int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
+    int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */
+    int32_t trace;                    /* 1: print what each call ran to stderr */
+} de_tuning;
+int de_get_tuning(de_ctx* ctx, de_tuning* out);
+int de_set_tuning(de_ctx* ctx, const de_tuning* in);
 /* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
  * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 37 MB per
  * launch slot whatever the call and is not affected): a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
@@ -260,12 +286,6 @@ int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
  * out[0..31] = lane / run counts per section, out[32..43] = shader cycles per section; n <= 48.  Index meaning:
  * tools/sched_stats.py.  Profiling aid only. */
 int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
-/* Statistics block of the persistent stage scheduler (kernel variant 5, environment DE_V5_STATS=1), summed over the launch slots'
- * last launches; n <= 40: [0..7] records taken per stage (sphere trace, gas, cloud, event, surface, volume finish, surface finish,
- * new paths), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] partial chunks published, [18] failed
- * claims, [19] stage entries, [20] refills from the device-wide free ring, [21] steals, [22] wave-time in the scheduler, [23] in next_input, [24] in pushes, [25] in loop-stage services, [26] in straight-line bodies, [27..30] of the scheduler's: free-chunk refill, age flush, queue snapshot, claim, [32..34] wave-trips of the three loop
- * stages, [35..37] their lane-trips, [38] times a loop stage found its queue dry.  Profiling aid. */
-int de_debug_v5_stats(de_ctx* ctx, uint64_t* out, int n);
 /* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 48: [0..7] records taken per stage
  * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
  * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [22] wave-time between the end of the work items and the wave's exit, [32..38] wave-trips of the loop

@@ -24,6 +24,7 @@ def _apply(r, preset):
     r.set_aspect_scale(p["aspect_scale"]); r.set_sun_angle(p["sun_angle"]); r.set_sun_path_rot(p["sun_path_rot"])
 
 
+@pytest.mark.legacy_quick
 @pytest.mark.parametrize("preset", [None, "config - florida.txt", "config - sunset hurricane.txt", "config - Apollo 11.txt"])
 def test_persistent_scheduler_matches_the_oracle(Renderer, lut_arrays, preset):
     W, H, SPP = 96, 48, 5

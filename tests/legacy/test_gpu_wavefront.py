@@ -29,6 +29,7 @@ def _apply(r, preset):
     r.set_aspect_scale(p["aspect_scale"]); r.set_sun_angle(p["sun_angle"]); r.set_sun_path_rot(p["sun_path_rot"])
 
 
+@pytest.mark.legacy_quick
 @pytest.mark.parametrize("preset", [None, "config - florida.txt", "config - sunset hurricane.txt", "config - Apollo 11.txt"])
 def test_wavefront_pipeline_matches_the_oracle(Renderer, lut_arrays, preset):
     W, H, SPP = 96, 48, 5
@@ -151,6 +152,7 @@ def test_automatic_variant_takes_the_pipeline_for_large_calls(Renderer, preset, 
     assert out[4][0].max() > 0
 
 
+@pytest.mark.legacy_quick
 def test_pipeline_with_finisher_matches_the_oracle(Renderer, lut_arrays, monkeypatch):
     """The hand-over from the pipeline to the state machine at every possible round (DE_AUTO_DEPTHS = 1 .. 4), forced on a small
     frame (DE_AUTO_MIN_ITEMS = 0) so that the oracle can render all of it: path rays queued for the next vertex are resumed by

@@ -126,8 +126,8 @@ def test_block_scheduler_overlapping_calls(Renderer):
 def test_the_default_variant_chooses_by_call_size(Renderer, monkeypatch):
     """The automatic variant (round 4): calls of at least 4096 paths run render_kernel_v6, in the reference's window loop (accumulate()
     then fetch_image(), earth_viewer.py:241-243) as well as back to back (tools/small_calls.py: it ends a call sooner than the state
-    machine from 4096 paths up); smaller calls run the state machine; DE_AUTO_V6=0 brings back the earlier policy (lone small calls
-    on render_kernel_v5).  Same bits every way."""
+    machine from 4096 paths up); smaller calls run the state machine (the earlier policy — lone small calls on render_kernel_v5 — lives in the legacy library:
+    tests/legacy/test_gpu_persistent.py).  Same bits every way."""
     kw = dict(seed=6, texture_source="synthetic", texture_size=(4096, 2048))
     W, H = 1024, 512                                              # 524 288 paths per sample
     a = Renderer((W, H), (0, 1, 0), **kw)
@@ -142,15 +142,9 @@ def test_the_default_variant_chooses_by_call_size(Renderer, monkeypatch):
     assert s.last_call_info()["variant"] == 2
     m = Renderer((64, 64), (0, 1, 0), **kw); m.accumulate(1)      # 4096 paths: the scheduler
     assert m.last_call_info()["variant"] == 6
-    monkeypatch.setenv("DE_AUTO_V6", "0")
-    b = Renderer((W, H), (0, 1, 0), **kw)
-    kinds = []
-    for _ in range(5):
-        b.accumulate(1); kinds.append(b.last_call_info()["variant"]); b.fetch_image()
-    assert kinds == [5] * 5, kinds
     c = Renderer((W, H), (0, 1, 0), **kw); c.set_kernel_variant(2); c.accumulate(5)
-    fa, fb, fc = a.fetch_hdr(), b.fetch_hdr(), c.fetch_hdr()
-    assert bits_equal_fraction(fa, fc) == 1.0 and bits_equal_fraction(fb, fc) == 1.0 and fc.max() > 0
+    fa, fc = a.fetch_hdr(), c.fetch_hdr()
+    assert bits_equal_fraction(fa, fc) == 1.0 and fc.max() > 0
 
 
 def test_block_scheduler_full_frame(Renderer):

@@ -223,30 +223,6 @@ def test_errors_are_reported(Renderer):
         Renderer((100, 50), (0, 1, 0), texture_source="constant")   # not a multiple of (16, 8), renderer.py:46
 
 
-@pytest.mark.parametrize("preset", [None, "config - sunset hurricane.txt"])
-def test_kernel_variants_agree(Renderer, preset):
-    """The wave-level state machine (variant 2, default) and the per-lane loop kernel (variant 1) are the same function."""
-    r = Renderer((128, 64), (0, 1, 0), texture_source="synthetic", texture_size=(2048, 1024), seed=3)
-    if preset:
-        p = load_preset(preset)
-        r.set_camera_pos(*p["pos"]); r.set_look_at(*p["look_at"]); r.set_up(*p["up"]); r.set_fov(p["fov"])
-        r.set_sun_angle(p["sun_angle"]); r.set_sun_path_rot(p["sun_path_rot"])
-    else:
-        r.set_fov(0.4)
-    out = {}
-    for variant in (1, 2):
-        r.set_kernel_variant(variant)
-        r.reset_framebuffer()
-        r.enable_counters(True)
-        r.accumulate(3)
-        cnt = r.counters(); cnt.pop("sched", None)
-        out[variant] = (r.fetch_hdr(), cnt, r.debug_samples(1))
-    assert (out[1][0].view(np.uint32) == out[2][0].view(np.uint32)).all()
-    for k in ("samples", "tracking_steps", "vertices", "rng_draws", "taps_rgb8"):
-        assert out[1][1][k] == out[2][1][k], k
-    assert out[2][1]["sphere_steps"] <= out[1][1]["sphere_steps"]      # variant 2 stops tracing rays that have escaped
-    assert (out[1][2].view(np.uint32) == out[2][2].view(np.uint32)).all()
-
 
 def test_fast_sqrt_is_correctly_rounded(Renderer):
     """de_sqrt_nr (v_rsq_f32 + one coupled Newton step) == IEEE sqrt for EVERY significand at both exponent parities

@@ -77,38 +77,3 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
     assert (o.fetch_hdr()[mask].view(np.uint32) == g[mask].view(np.uint32)).all()
     assert np.abs(o.fetch_image()[mask] - img[mask]).max() <= 1e-5
     assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01
-
-
-def test_memory_budget_cuts_the_batches_not_the_bits(Renderer, monkeypatch):
-    """de_set_memory_budget on the wavefront pipeline — the automatic variant's choice for large calls until the per-CU
-    stage scheduler took over (which holds 37 MB per launch slot whatever the call: tests/test_gpu_block_scheduler.py); DE_AUTO_V6=0
-    selects that policy.  1920x1088 x 64 spp = 134 M paths in two batches on two pipes, 512 B per path and pipe plus
-    each pipe's room for holes (1.9 GB): 72 GB.  With 60 GB the pipes get 30 GB each: the batches shrink (more launches), the memory
-    held stays inside the budget, the frame is the state machine's bit for bit; with a budget that leaves a pipe room for less than a
-    worthwhile batch the call runs on the state machine, in one launch."""
-    from helpers import bits_equal_fraction
-    monkeypatch.setenv("DE_AUTO_V6", "0")
-    W, H, SPP = 1920, 1088, 64
-    kw = dict(seed=17, texture_source="synthetic", texture_size=(4096, 2048))
-    ref = Renderer((W, H), (0, 1, 0), **kw); ref.set_kernel_variant(2); ref.accumulate(SPP)
-    want = ref.fetch_hdr()
-    r = Renderer((W, H), (0, 1, 0), **kw)
-    r.accumulate(SPP); r.synchronize()
-    free_launches, free_bytes = r.last_call_info()["launches"], r.memory_use()
-    assert r.last_call_info()["variant"] == 3 and free_bytes > 0
-    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
-    budget = 60 << 30
-    r.set_memory_budget(budget)
-    assert r.memory_use() == 0                                   # setting it releases what was held
-    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
-    info = r.last_call_info()
-    assert info["variant"] == 3 and info["launches"] > free_launches, (info, free_launches)
-    assert 0 < r.memory_use() <= budget
-    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
-    r.set_memory_budget(8 << 30)                                 # 4 GB per pipe: 4 M paths, not worth a pipeline launch
-    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
-    assert r.last_call_info()["variant"] == 2 and r.last_call_info()["launches"] == 1 and r.memory_use() == 0
-    assert bits_equal_fraction(r.fetch_hdr(), want) == 1.0
-    r.set_memory_budget(0)
-    r.reset_framebuffer(); r.accumulate(SPP); r.synchronize()
-    assert r.last_call_info()["launches"] == free_launches
