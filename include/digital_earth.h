@@ -231,15 +231,13 @@ int de_enable_counters(de_ctx* ctx, int enable);
 /* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
  *   4 (default)  automatic: a call of at least 4096 paths runs the per-CU stage scheduler (variant 6) in one launch per 2^29 paths; smaller
  *                calls (and counting launches) run the state machine (variant 2), overlapping through the launch slots.  The choice
- *                depends on the call's size only and moves time, never bits.  (Environment DE_AUTO_V6=0: the policy of rounds 3-4 — the
- *                first vertex rounds of a large call in the wavefront pipeline, batches side by side, the surviving paths in the state
- *                machine; mid-size calls on four pipes; lone small calls on variant 5.)
+ *                depends on the call's size only and moves time, never bits.
  *   2            wave-level state machine only (render_kernel_v2.hip)
- *   3            wavefront pipeline through HBM stage queues (render_kernel_v3.hip), all 25 rounds unless DE_V3_DEPTHS
- *   1            per-lane loops (render_kernel.hip)
- *   5            persistent stage scheduler: ONE launch whose waves pick the fullest of seven chunked HBM queues (render_kernel_v5.hip)
  *   6            per-CU stage scheduler: ONE launch, two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
- * The ray marcher always runs its own kernel.  Environment DE_KERNEL=1..6 selects the variant at de_create. */
+ * Variants 1 (per-lane loops), 3 (wavefront pipeline through HBM stage queues; with DE_AUTO_V6=0 the launch policy of rounds 3-4) and 5 (stage
+ * scheduler over HBM queues) are further statements of path_tracer kept for the cross-check tests: the LEGACY library only
+ * (libdigitalearth_hip_legacy.so, include/digital_earth_legacy.h); this library answers DE_ERR_INVALID to them.
+ * The ray marcher always runs its own kernel. */
 int de_set_kernel_variant(de_ctx* ctx, int variant);
 
 /* Tuning of the product's kernels as one plain struct — the library reads NO environment variable for any of this (the only ones it
@@ -255,6 +253,7 @@ typedef struct de_tuning {
     int32_t v6_service_lanes[3];      /* ... idle lanes at which it does (the rule of round 4) */
     int32_t v6_yield_max, v6_elsewhere_min, v6_retry, v6_enter_min, v6_flat_min, v6_flat_again;   /* render_kernel_v6.hip: bs::Args */
     int32_t v6_bands;                 /* 8: one work counter per XCD, each over its own band of the launch's tiles (default); 1: one counter */
+    int32_t v6_st_dual;               /* 1: the sphere-trace stage steps two records per lane (both map taps in flight before either texel is used) */
     int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
     int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */
     int32_t trace;                    /* 1: print what each call ran to stderr */
@@ -269,9 +268,10 @@ int de_set_tuning(de_ctx* ctx, const de_tuning* in);
  * de_get_memory_use: bytes currently held for these buffers. */
 int de_set_memory_budget(de_ctx* ctx, uint64_t bytes);
 int de_get_memory_use(de_ctx* ctx, uint64_t* queue_bytes);
-/* What the last de_accumulate call ran (any pointer may be NULL): *variant = the kernel of its launches (1, 2, 3 = the wavefront pipeline —
- * with the state machine as finisher when *depths < 25 —, 5 = the persistent stage scheduler, 0 = the ray marcher), *pipes = pipelines side
- * by side, *depths = vertex rounds run in the pipeline, *launches = launches the call was cut into.  For a host that reports what it measured. */
+/* What the last de_accumulate call ran (any pointer may be NULL): *variant = the kernel of its launches (6 = the per-CU stage scheduler, 2 = the
+ * state machine, 0 = the ray marcher; in the legacy library also 1, 3 = the wavefront pipeline — with the state machine as finisher when
+ * *depths < 25 —, 5 = the HBM-queue scheduler), *pipes = pipelines side by side (legacy; 1 otherwise), *depths = vertex rounds run in the
+ * pipeline (legacy; 0 otherwise), *launches = launches the call was cut into.  For a host that reports what it measured. */
 int de_last_call_info(de_ctx* ctx, int* variant, int* pipes, int* depths, int* launches);
 
 /* Debug / test hooks.

@@ -26,8 +26,8 @@ def _apply(r, name, crf_by_name=None):
 @pytest.mark.timeout(3000)
 def test_cfg4_quality2_cloud_heavy_full_sample_count(Renderer, lut_arrays):
     """BASELINE configs[3]: 3840x2160, 128 spp, `config - sunset hurricane.txt`, the quality-2 tier (lib/textures.py:65-79:
-    21600x10800 / 16200x8100) with the cloud-heavy stand-in maps.  The oracle renders every 97th 8x8 tile of the same frame at all
-    128 spp (1.06 G paths on the GPU, 11 M on the host); those pixels match bit for bit."""
+    21600x10800 / 16200x8100) with the cloud-heavy stand-in maps.  The oracle renders every 293rd 8x8 tile of the same frame at all
+    128 spp (1.06 G paths on the GPU, 3.6 M on the host: the oracle is what this test waits for); those pixels match bit for bit."""
     from digital_earth_amd import parallel
     W, H, SPP = 3840, 2160, 128
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_quality=2, cloud_heavy=True, seed=7)
@@ -38,9 +38,9 @@ def test_cfg4_quality2_cloud_heavy_full_sample_count(Renderer, lut_arrays):
     g = r.fetch_hdr()
     assert r.current_spp == SPP and np.isfinite(g).all() and g.max() > 0
     o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
-    o.accumulate(SPP, 7, 23, 97)
-    mask = parallel.owned_pixel_mask(W, H, 23, 97)
-    assert mask.sum() >= 80000
+    o.accumulate(SPP, 7, 23, 293)
+    mask = parallel.owned_pixel_mask(W, H, 23, 293)
+    assert mask.sum() >= 27000
     assert (o.fetch_hdr()[mask].view(np.uint32) == g[mask].view(np.uint32)).all()
     img = r.fetch_image()
     assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01
@@ -51,7 +51,7 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
     """BASELINE configs[4]: 1920x1080, 1024 spp PROGRESSIVE (a display after every 128 samples), `config - Apollo 11.txt`, quality-2
     maps, the camera-response curve selected BY NAME — the preset's index 12 counts os.listdir order on the author's machine (Q10):
     the curve is taken by the name the executed-reference fixtures carry for this preset, not by the index.
-    Oracle: every 97th tile at all 1024 spp, HDR bit for bit, and the displayed pixels through the same film curve."""
+    Oracle: every 193rd tile at all 1024 spp, HDR bit for bit, and the displayed pixels through the same film curve."""
     import os
     from digital_earth_amd import parallel
     from test_ref_fixtures import GOLDEN
@@ -71,9 +71,9 @@ def test_cfg5_quality2_progressive_with_the_film_curve_by_name(Renderer, lut_arr
     assert len(shown) == SPP // EVERY and np.isfinite(g).all() and g.max() > 0
     assert abs(shown[-1] - shown[-2]) < 0.005 * shown[-1] and max(shown) < 1.05 * min(shown)   # the display converges; it does not brighten with the sample count
     o = make_oracle(W, H, lut_arrays, [r.download_texture(s) for s in range(7)], r._params)
-    o.accumulate(SPP, 13, 41, 97)
-    mask = parallel.owned_pixel_mask(W, H, 41, 97)
-    assert mask.sum() >= 20000
+    o.accumulate(SPP, 13, 41, 193)
+    mask = parallel.owned_pixel_mask(W, H, 41, 193)
+    assert mask.sum() >= 10000
     assert (o.fetch_hdr()[mask].view(np.uint32) == g[mask].view(np.uint32)).all()
     assert np.abs(o.fetch_image()[mask] - img[mask]).max() <= 1e-5
     assert img.min() >= 0.0 and img.max() <= 1.0 and img.std() > 0.01

@@ -165,9 +165,10 @@ def test_launch_phases_and_zero_copy_image_lifetime(Renderer):
 @pytest.mark.timeout(900)
 def test_fast_math_flag_is_statistically_the_same_image(Renderer):
     """DE_FLAG_FAST_MATH (opt-in): the same integrator on the hardware's transcendental units.  Not bit-reproducible — a sample whose collision
-    test lands on the other side follows another path — so the tolerance is statistical: at 1 spp fewer than 2 % of the samples take another
-    path, the others agree to 1e-3 relative (roundings); the mean radiance of a 64-spp frame agrees to 1 %, and the frame differs from
-    the contract's by less than two renders of the contract's kernel with different seeds differ (the flag moves samples, not the estimate).
+    test lands on the other side follows another path (a path takes ~150 such tests: measured 5-14 % of the samples per camera,
+    profiles/r5_fast_math.md) — so the tolerance is statistical: at 1 spp fewer than 25 % of the samples take another path, the others agree
+    to 1e-3 relative (roundings); the mean radiance of a 64-spp frame agrees to 1 %, and the frame differs from the contract's by less than
+    two renders of the contract's kernel with different seeds differ (the flag moves samples, not the estimate).
     The default (flag off) stays the arithmetic contract: bit-identical to the oracle (every other test)."""
     kw = dict(texture_source="synthetic", texture_size=(2048, 1024))
     frames = {}
@@ -188,6 +189,6 @@ def test_fast_math_flag_is_statistically_the_same_image(Renderer):
     one_f, f_f = frames["fast"]
     lit = np.maximum(one_c, one_f) > 0
     moved = np.abs(one_f - one_c) > 1e-3 * np.maximum(np.abs(one_c), np.abs(one_f))
-    assert lit.sum() > 5000 and (moved & lit).sum() < 0.02 * lit.sum()
+    assert lit.sum() > 5000 and 0 < (moved & lit).sum() < 0.25 * lit.sum()
     assert abs(f_f.sum() / f_c.sum() - 1.0) < 0.01
     assert rel_l2(f_f, f_c) < rel_l2(frames["other seed"][1], f_c)

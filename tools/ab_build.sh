@@ -7,5 +7,5 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/build/ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wno-unused-value "$@" \
-  $ROOT/digital_earth_amd/csrc/de_api.hip -o $ROOT/build/ab/$NAME.so
+  $ROOT/digital_earth_amd/csrc/de_api.hip $ROOT/digital_earth_amd/csrc/de_fast.hip -o $ROOT/build/ab/$NAME.so
 echo built $ROOT/build/ab/$NAME.so
