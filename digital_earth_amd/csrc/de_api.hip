@@ -514,7 +514,7 @@ int de_get_tuning(de_ctx* c, de_tuning* t) {
     t->v6_min_paths = (uint64_t)c->auto_v6_min_items;
     for (int k = 0; k < 3; ++k) { t->v6_service_area[k] = c->v6_svc_area[k]; t->v6_service_lanes[k] = c->v6_svc[k]; }
     t->v6_yield_max = c->v6_yield; t->v6_elsewhere_min = c->v6_elsewhere; t->v6_retry = c->v6_retry; t->v6_enter_min = c->v6_enter_min;
-    t->v6_flat_min = c->v6_flat_min; t->v6_flat_again = c->v6_flat_again; t->v6_bands = c->v6_bands; t->v6_st_dual = c->v6_st_dual; t->v6_stats = c->v6_stats;
+    t->v6_flat_min = c->v6_flat_min; t->v6_flat_again = c->v6_flat_again; t->v6_bands = c->v6_bands; t->v6_stats = c->v6_stats;
     t->v2_pend = c->tune_pend; t->v2_heavy = c->tune_heavy; t->v2_b = c->tune_b; t->v2_gas = c->tune_gas; t->v2_chunk = c->tune_chunk;
     t->v2_waves_per_cu = c->tune_wpc; t->v2_max_spp = c->tune_max_spp;
     t->trace = c->trace ? 1 : 0;
@@ -532,7 +532,7 @@ int de_set_tuning(de_ctx* c, const de_tuning* t) {
     c->auto_v6_min_items = (unsigned long long)t->v6_min_paths;
     for (int k = 0; k < 3; ++k) { c->v6_svc_area[k] = t->v6_service_area[k]; c->v6_svc[k] = t->v6_service_lanes[k]; }
     c->v6_yield = t->v6_yield_max; c->v6_elsewhere = t->v6_elsewhere_min; c->v6_retry = t->v6_retry; c->v6_enter_min = t->v6_enter_min;
-    c->v6_flat_min = t->v6_flat_min; c->v6_flat_again = t->v6_flat_again; c->v6_bands = t->v6_bands == 8 ? 8 : 1; c->v6_st_dual = t->v6_st_dual != 0; c->v6_stats = t->v6_stats;
+    c->v6_flat_min = t->v6_flat_min; c->v6_flat_again = t->v6_flat_again; c->v6_bands = t->v6_bands == 8 ? 8 : 1; c->v6_stats = t->v6_stats;
     c->tune_pend = t->v2_pend; c->tune_heavy = t->v2_heavy; c->tune_b = t->v2_b; c->tune_gas = t->v2_gas; c->tune_chunk = t->v2_chunk;
     c->tune_wpc = t->v2_waves_per_cu; c->tune_max_spp = t->v2_max_spp;
     c->trace = t->trace != 0;

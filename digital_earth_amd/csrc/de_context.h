@@ -125,7 +125,6 @@ struct de_ctx {
         uint32_t n_wg = 0;
     } v6s[DE_MAX_SLOTS];
     int v6_bands = 8;                // work counters of a launch: 8 = one band of the image per XCD, 1 = one for the whole launch (render_kernel_v6.hip: run_primary)
-    int v6_st_dual = 0;              // 1: the sphere-trace stage of render_kernel_v6 steps two records per lane (run_st2)
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v6_svc[3] = {24, 24, 20};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)
     int v6_svc_area[3] = {100, 72, 90};  // idle lane-trips since its last service at which a loop stage services (sphere trace, gas, cloud; 0 = the idle-lane threshold above): render_kernel_v6.hip run_loop

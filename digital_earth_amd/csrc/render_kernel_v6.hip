@@ -111,7 +111,6 @@ struct Args {
     uint32_t flat_min;          // a straight-line stage is entered with fewer entries than this only when the loop stages' rings are empty (0: off; measured flat)
     uint32_t flat_again;        // a straight-line stage runs a FURTHER pass only when its ring holds at least this many entries (1: until the ring is dry)
     uint32_t bands;             // work counters: 8 = one band of the image per XCD (run_primary), 1 = one counter for the whole launch
-    uint32_t st_dual;           // 1: the sphere-trace stage steps two records per lane (run_st2)
 };
 template <int... T> struct Targets {};
 
@@ -128,7 +127,6 @@ struct Cfg {
     uint32_t yield_max, elsewhere_min, retry, enter_min;
     uint32_t flat_min, flat_again;
     uint32_t bands, xcd;        // xcd: the XCD this workgroup runs on (HW_REG_XCC_ID)
-    uint32_t st_dual;
 };
 static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 128, "Cfg is copied dword by dword");
 
@@ -469,108 +467,6 @@ struct Wave {
         tick<R_HEAD>(0ull);
         regions_end_loop(Q);
     }
-    // ---- the sphere trace with TWO records per lane (round 5, experiment: Args::st_dual).  A sphere-trace step is ~65 instructions around ONE dependent
-    // map tap whose position depends on the previous tap's texel: a wave of this stage waits for memory three quarters of its time (1.7 us per trip
-    // where its instructions need 0.4), and it holds its 64 record slots and a sixth of a SIMD's wave slots while it does.  Here a lane steps two
-    // records side by side — both taps issued before either texel is used — so a trip serves 128 records in the time of one wait.  A record's
-    // live state in the loop is P, W, t and the step count; everything else stays in its LDS slot and is read again by the epilogue.
-    template <typename St>
-    DE_DEV void run_st2(const St& proto) {
-        const float MAXD = proto.max_ray_dist;
-        St st0 = proto, st1 = proto;
-        Path p0, p1;
-        uint32_t slot0 = 0, slot1 = 0;
-        bool busy0 = false, busy1 = false, fin0 = false, fin1 = false;
-        const uint32_t AREA = A.svc_area[Q_ST] != 0u ? 2u * A.svc_area[Q_ST] : 0u;
-        const int SERVICE = 2 * (int)A.svc[Q_ST];
-        uint32_t idle_acc = 0, trips = 0, retry_at = 0;
-        bool dry = false;
-        const unsigned long long lt = (1ull << lane_id()) - 1ull;
-        auto finish2 = [&](Path& pl, St& st, uint32_t slot, bool& fin) {
-            if (__ballot(fin) == 0ull) return;
-            int target = -1;
-            if (fin) {
-                Path p;
-                load_rec(rec, slot, p);
-                target = wf::after_sphere_trace(p, st.t, MAXD);
-                store_rec(rec, slot, p);
-            }
-            release_wg();
-            push<Q_GAS>(slot, fin && target == Q_GAS); push<Q_CLOUD>(slot, fin && target == Q_CLOUD);
-            push<Q_EVENT>(slot, fin && target == Q_EVENT); push<Q_SURFFIN>(slot, fin && target == Q_SURFFIN);
-            fin = false;
-            (void)pl;
-        };
-        auto begin2 = [&](Path& pl, St& st, uint32_t s) {
-            Path p;
-            load_rec(rec, s, p);
-            pl.P = p.P; pl.W = p.W;
-            st.begin(p);
-            if ((p.meta & 0x80000000u) != 0u) {
-                st.restore(cold + s);
-                reinterpret_cast<uint32_t*>(rec + s)[0] = p.meta & 0x7fffffffu;      // the record's meta word: "resume" taken
-            }
-        };
-        auto suspend2 = [&](St& st, uint32_t s, bool busy) {
-            if (!busy) return;
-            reinterpret_cast<float*>(rec + 2u * DE_V6_P + s)[1] = st.t;              // x[0]: where begin() reads t from
-            cold[s].pad1 = wf::asf((uint32_t)st.cnt);
-            reinterpret_cast<uint32_t*>(rec + s)[0] |= 0x80000000u;
-        };
-        for (;;) {
-            const int nb = __popcll(__ballot(busy0)) + __popcll(__ballot(busy1));
-            const bool may_refill = !dry || trips >= retry_at;
-            idle_acc += (uint32_t)(128 - nb);
-            const bool fin_any = __ballot(fin0 || fin1) != 0ull;
-            const bool due = AREA != 0u ? idle_acc >= AREA : 128 - nb >= SERVICE;
-            if (nb == 0 || (due && (may_refill || fin_any))) {
-                idle_acc = 0u;
-                if (fin_any) { finish2(p0, st0, slot0, fin0); finish2(p1, st1, slot1, fin1); }
-                if (may_refill || nb == 0) {
-                    dry = false;
-                    const unsigned long long m0 = __ballot(!busy0), m1 = __ballot(!busy1);
-                    const uint32_t need0 = (uint32_t)__popcll(m0), need1 = (uint32_t)__popcll(m1);
-                    uint32_t first = 0;
-                    const uint32_t got = claim(Q_ST, 1u, need0 + need1, &first);
-                    if (got == 0u) {
-                        dry = true; retry_at = trips + A.retry;
-                        if (nb > 0 && nb <= 2 * (int)A.yield_max && work_elsewhere(Q_ST)) {
-                            suspend2(st0, slot0, busy0); suspend2(st1, slot1, busy1);
-                            release_wg();
-                            push<Q_ST>(slot0, busy0); push<Q_ST>(slot1, busy1);
-                            stat(ST_YIELD, 1); stat(ST_YIELDED, (unsigned long long)nb);
-                            busy0 = busy1 = false;
-                            break;
-                        }
-                    } else {
-                        const uint32_t my0 = (uint32_t)__popcll(m0 & lt), n0 = got < need0 ? got : need0;
-                        const uint32_t my1 = n0 + (uint32_t)__popcll(m1 & lt);
-                        const bool mine0 = !busy0 && my0 < n0, mine1 = !busy1 && my1 < got;
-                        uint32_t s0 = 0, s1 = 0;
-                        if (mine0) s0 = take(Q_ST, first + my0);
-                        if (mine1) s1 = take(Q_ST, first + my1);
-                        if (__ballot((mine0 && s0 == DE_V6_EMPTY) || (mine1 && s1 == DE_V6_EMPTY)) != 0ull) { raise(ERR_ENTRY_TIMEOUT); break; }
-                        acquire_wg();
-                        if (mine0) { slot0 = s0; begin2(p0, st0, s0); busy0 = true; }
-                        if (mine1) { slot1 = s1; begin2(p1, st1, s1); busy1 = true; }
-                        stat(ST_RECS + Q_ST, got);
-                    }
-                }
-                if (__ballot(busy0 || busy1) == 0ull) { if (dry || aborted) break; else continue; }
-            }
-            if (STATS) { stat(ST_TRIPS + Q_ST, 1); stat(ST_LANETRIPS + Q_ST, (unsigned long long)(__popcll(__ballot(busy0)) + __popcll(__ballot(busy1))) / 2ull); }
-            typename St::Tok k0, k1;
-            bool e0 = false, e1 = false;
-            if (busy0) e0 = st0.issue(p0, k0);
-            if (busy1) e1 = st1.issue(p1, k1);
-            if (busy0 && !e0) e0 = st0.resolve(p0, k0);
-            if (busy1 && !e1) e1 = st1.resolve(p1, k1);
-            if (e0) { busy0 = false; fin0 = true; }
-            if (e1) { busy1 = false; fin1 = true; }
-            trips++;
-        }
-    }
-
     // is there a wave-load of work outside ring q (another stage's ring, or free slots for new paths)?
     DE_DEV bool work_elsewhere(uint32_t q) {
         int ready = 0;
@@ -705,17 +601,6 @@ DE_V6_STAGE v6_stage_st(bool primary_left) {
     StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
     W.template run_loop<Q_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
 }
-DE_V6_STAGE v6_stage_st2(bool primary_left) {      // the same stage, two records per lane (Args::st_dual)
-    using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
-    const RenderArgs& a = *W.A.ra;
-    const FrameConsts& fc = *W.A.fc;
-    const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
-    TexR8 topo = a.topo;
-    topo.data = uni_ptr(topo.data);      // the base in scalar registers (two records' address arithmetic leaves no room for it in the vector file); the other fields stay vector: see v6_stage_st
-    StStage<CLAMP> st{topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
-    W.run_st2(st);
-}
 DE_V6_STAGE v6_stage_gas(bool primary_left) {
     using namespace bs;
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
@@ -775,7 +660,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         c.svc[0] = A.svc[0]; c.svc[1] = A.svc[1]; c.svc[2] = A.svc[2];
         c.svc_area[0] = A.svc_area[0]; c.svc_area[1] = A.svc_area[1]; c.svc_area[2] = A.svc_area[2];
         c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.flat_min = A.flat_min; c.flat_again = A.flat_again;
-        c.bands = A.bands == 8u ? 8u : 1u; c.st_dual = A.st_dual;
+        c.bands = A.bands == 8u ? 8u : 1u;
         { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); c.xcd = xcc & 7u; }
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];
@@ -795,7 +680,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
             break;
         }
         switch (s) {
-        case Q_ST: if (W.A.st_dual != 0u) v6_stage_st2<CLAMP, STATS>(W.primary_left); else v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
+        case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
         case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;
         case Q_CLOUD: v6_stage_cloud<CLAMP, STATS>(W.primary_left); W.template mark<Q_CLOUD>(); break;
         case Q_EVENT: v6_stage_event<CLAMP, STATS>(W.primary_left); W.template mark<Q_EVENT>(); break;

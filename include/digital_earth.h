@@ -253,7 +253,6 @@ typedef struct de_tuning {
     int32_t v6_service_lanes[3];      /* ... idle lanes at which it does (the rule of round 4) */
     int32_t v6_yield_max, v6_elsewhere_min, v6_retry, v6_enter_min, v6_flat_min, v6_flat_again;   /* render_kernel_v6.hip: bs::Args */
     int32_t v6_bands;                 /* 8: one work counter per XCD, each over its own band of the launch's tiles (default); 1: one counter */
-    int32_t v6_st_dual;               /* 1: the sphere-trace stage steps two records per lane (both map taps in flight before either texel is used) */
     int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
     int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */
     int32_t trace;                    /* 1: print what each call ran to stderr */
