@@ -428,30 +428,34 @@ struct GasStage {
 #endif
         const vec3 es = v3(ext_r, ext_m, ext_o) * dens;
         const float sum = (es.x + es.y) + es.z;
-        if (kind == 0) {
-            const float rand = rng_next(p.rng);
-            if (rand < sum * rmaxr) {
-                int id = 0;
-                float cmf = es.x;
+        // delta tracking (kind 0) draws, ratio tracking (kinds 1, 2) multiplies — as selects, for the reason given in CloudStage::resolve: the draw is made
+        // on a copy of the generator and committed for kind-0 lanes only; the rare collision (species walk, scatter / absorb draw) keeps its branch
+        const float pr = sum * rmaxr;
+        const bool delta = kind == 0;
+        Rng g = p.rng;
+        const float rand = rng_next(g);
+        p.rng.s0 = delta ? g.s0 : p.rng.s0; p.rng.s1 = delta ? g.s1 : p.rng.s1;
+        const float trn_r = trn * (1.0f - pr);
+        trn = delta ? trn : trn_r;
+        bool done = !delta & (trn_r < 1e-5f);
+        if (delta & (rand < pr)) {
+            int id = 0;
+            float cmf = es.x;
+            if (!(rand < cmf * rmaxr)) {
+                id = 1;
+                cmf += es.y;
                 if (!(rand < cmf * rmaxr)) {
-                    id = 1;
-                    cmf += es.y;
-                    if (!(rand < cmf * rmaxr)) {
-                        id = 2;
-                        cmf += es.z;
-                        if (!(rand < cmf * rmaxr)) id = 3;
-                    }
+                    id = 2;
+                    cmf += es.z;
+                    if (!(rand < cmf * rmaxr)) id = 3;
                 }
-                const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));
-                event = (rng_next(p.rng) < albedo) ? wf::EV_SCATTER : wf::EV_ABSORB;
-                ev_id = id;
-                return true;
             }
-        } else {
-            trn *= 1.0f - sum * rmaxr;
-            if (trn < 1e-5f) return true;
+            const float albedo = (id == 0) ? 1.0f : ((id == 1) ? 0.95f : ((id == 2) ? 0.0f : 0.99f));
+            event = (rng_next(p.rng) < albedo) ? wf::EV_SCATTER : wf::EV_ABSORB;
+            ev_id = id;
+            done = true;
         }
-        return !(t < tmax);                                                  // loop-head test (differs from the above only for NaN)
+        return done | !(t < tmax);                                           // loop-head test (differs from "no event" only for NaN)
     }
     DE_DEV int finish(wf::Path& p) {
         // rmo_event / rmo_t / ev_id (delta) or trg = trn (ratio), then the cloud-shell segment of the same ray
@@ -511,17 +515,23 @@ struct CloudStage {
             const float tex = tap_r8_finish(k.q, k.fx, k.fy);
             const float h = k.h;
             const float split = 0.2f;
-            density = (h - split < tex * (float)(1.0 - 0.2) && split - h < tex * split) ? de_max(tex, 0.4f) : 0.0f;
+            density = ((h - split < tex * (float)(1.0 - 0.2)) & (split - h < tex * split)) ? de_max(tex, 0.4f) : 0.0f;      // both tests always: no short-circuit branch
         }
         const float es = ext_w * (density * DE_CLOUDS_DENSITY);
-        if (kind == 0) {
-            const float rand = rng_next(p.rng);
-            if (rand < es * rmaxc) { cloud_event = (rng_next(p.rng) < 0.99f) ? wf::EV_SCATTER : wf::EV_ABSORB; return true; }
-        } else {
-            trn *= 1.0f - es * rmaxc;
-            if (trn < 1e-5f) return true;
-        }
-        return !(t < tmax);
+        // delta tracking (kind 0) draws, ratio tracking (kinds 1, 2) multiplies: the same statements as a literal `if (kind == 0) ... else ...`, written as
+        // selects — a wave of this stage holds both kinds, so both sides run either way, and the divergent form pays a dozen scalar instructions of
+        // exec-mask bookkeeping per step on top (this kernel pays for instructions, scalar ones included).  The draw is made on a copy of the generator
+        // and committed for kind-0 lanes only; the rare collision keeps its branch.
+        const float pr = es * rmaxc;
+        const bool delta = kind == 0;
+        Rng g = p.rng;
+        const float rand = rng_next(g);
+        p.rng.s0 = delta ? g.s0 : p.rng.s0; p.rng.s1 = delta ? g.s1 : p.rng.s1;
+        const float trn_r = trn * (1.0f - pr);
+        trn = delta ? trn : trn_r;
+        bool done = !delta & (trn_r < 1e-5f);
+        if (delta & (rand < pr)) { cloud_event = (rng_next(p.rng) < 0.99f) ? wf::EV_SCATTER : wf::EV_ABSORB; done = true; }
+        return done | !(t < tmax);
     }
     DE_DEV bool step(wf::Path& p) { Tok k; return issue(p, k) || resolve(p, k); }
     DE_DEV int finish(wf::Path& p) {

@@ -392,10 +392,13 @@ struct Wave {
         regions_begin();
         for (;;) {
             const int nb = __popcll(__ballot(busy));
-            const bool may_refill = !dry || trips >= retry_at;
             idle_acc += (uint32_t)(64 - nb);
-            const bool due = AREA != 0u ? idle_acc >= AREA : 64 - nb >= SERVICE;
-            if (nb == 0 || (due && (may_refill || __ballot(fin) != 0ull))) {
+            // ONE compare per trip on the common path (a wave without busy lanes gets here within two trips: 64 idle lane-trips each); whether a
+            // service can do anything — a ring to refill from, finished records to pass on — is only asked once one is due.  Measured (same box,
+            // profiles/experiments): with the four-way condition evaluated every trip the frame executes 4.7 % more vector and 17 % more scalar
+            // instructions (the compiler's code for the loop carries more copies around a wider head): cfg2 108.9 -> 105.8 ms, limb view 317 -> 300
+            const bool may_refill = !dry || trips >= retry_at;
+            if (idle_acc >= AREA && (nb == 0 || ((AREA != 0u || 64 - nb >= SERVICE) && (may_refill || __ballot(fin) != 0ull)))) {
                 idle_acc = 0u;
                 tick<R_HEAD>(0ull);
                 if (STATS) r_cnt[0]++;
