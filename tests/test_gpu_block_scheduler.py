@@ -45,15 +45,21 @@ def test_block_scheduler_matches_the_oracle(Renderer, lut_arrays, preset):
     assert got.max() > 0
 
 
-@pytest.mark.parametrize("yield_max,svc,retry,elsewhere,enter_min", [(0, 16, 6, 48, 0), (63, 1, 1, 1, 0), (63, 48, 2, 1, 0), (32, 8, 12, 200, 64), (56, 63, 1, 16, 32)])
-def test_block_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, yield_max, svc, retry, elsewhere, enter_min):
-    """No yields at all; a wave that hands its records back whenever its ring is dry and services after every finished record
-    (each record is suspended and resumed many times); late services; a scheduler that leaves shallow rings alone: the frame is the
-    state machine's, bit for bit.  1.4 M paths on 512 workgroups of 1120 slots: every slot is reused ~3 times per launch."""
+@pytest.mark.parametrize("yield_max,svc,area,retry,elsewhere,enter_min,flat_again,bands",
+                         [(0, 16, 0, 6, 48, 0, 1, 1), (63, 1, 1, 1, 1, 0, 1, 8), (63, 48, 5000, 2, 1, 0, 64, 8), (32, 8, 0, 12, 200, 64, 16, 1), (56, 63, 400, 1, 16, 32, 32, 8)])
+def test_block_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, yield_max, svc, area, retry, elsewhere, enter_min, flat_again, bands):
+    """No yields at all; a wave that hands its records back whenever its ring is dry and services after every trip with an idle lane
+    (each record is suspended and resumed many times); services by idle lane-trips (the shipped rule: area > 0) at both extremes and by
+    idle lanes (round 4's rule: area = 0); further straight-line passes from 1 / 16 / 32 / 64 entries; one work counter or one per XCD; a
+    scheduler that leaves shallow rings alone: the frame is the state machine's, bit for bit.  1.4 M paths on 512 workgroups of 1120 slots:
+    every slot is reused ~3 times per launch.  (The knobs travel as ONE de_set_tuning call: the Python layer reads these variables, the
+    library reads none.)"""
     monkeypatch.setenv("DE_V6_YIELD", str(yield_max)); monkeypatch.setenv("DE_V6_RETRY", str(retry))
     monkeypatch.setenv("DE_V6_ELSEWHERE", str(elsewhere)); monkeypatch.setenv("DE_V6_ENTER_MIN", str(enter_min))
+    monkeypatch.setenv("DE_V6_FLAT_AGAIN", str(flat_again)); monkeypatch.setenv("DE_V6_BANDS", str(bands))
     for k in ("ST", "GAS", "CLOUD"):
         monkeypatch.setenv("DE_V6_SVC_" + k, str(svc))
+        monkeypatch.setenv("DE_V6_AREA_" + k, str(area))
     W, H, SPP = 640, 360, 12
     kw = dict(seed=5, texture_source="synthetic", texture_size=(4096, 2048))
     out = {}
