@@ -6,8 +6,21 @@ variants 2 / 5: one render_kernel_v2 / v5_kernel launch); with the wavefront pip
 sequence: batches side by side, each = the pipeline's stage kernels for the first vertex rounds (v3_*) + render_kernel_v2 as finisher.
 Counters are therefore summed over ALL render kernels of a run and divided by its number of frames; the frame duration is the busy span
 of the render kernels in the kernel trace between two display_kernel launches."""
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
 from collections import defaultdict
+
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the device and host sources of the library, in name order: what the profiled counters belong to.  bench.py
+    recomputes it and withholds replayed counters when the sources have changed since the profile (box-to-box speed differences of 5 % were measured
+    for one build in round 5: a duration gate alone either passes changed kernels or refuses unchanged ones)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "digital_earth_amd", "csrc")
+    h = hashlib.sha256()
+    for d, _, files in sorted(os.walk(root)):
+        for f in sorted(files):
+            if f.endswith((".h", ".hip", ".inc")):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 RENDER = re.compile(r"render_kernel|ray_march_kernel|v3_|v5_kernel|v6_kernel")
 
@@ -128,6 +141,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                            "fetch_raw_bytes": fetch_kb * 1024, "fetch_x2_bytes": 2 * fetch_kb * 1024, "write_bytes": wr_kb * 1024,
                            "tcc_miss_x_128B": (miss * 128 if miss else None), "profile": tag, "kernel_ms": kernel_ms,
                            "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": lane,
+                           "salu_insts_per_launch": means.get("SQ_INSTS_SALU"), "source_sha16": source_sha16(),
                            "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), summed over every render kernel of a frame (one "
                                    "de_accumulate(64) call: one v6_kernel launch under the default variant); read bytes = 2 x FETCH_SIZE (a request "
                                    "moves a 128-B line and is tallied as 64 B: profiles/r2_fetch_calibration). L2-miss traffic at the fabric: "
