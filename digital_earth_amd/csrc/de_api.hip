@@ -593,6 +593,7 @@ int de_debug_v6_stats(de_ctx* c, uint64_t* out, int n) {
         HIP_TRY(hipMemcpy(h.data(), S.ctl, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (int k = 0; k < n && k < bs::ST_N; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_STAT0 + k) * DE_V6_CTL_STRIDE], 8); out[k] += v; }
         for (int k = 64; k < n && k < 128; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_STAT2 + k - 64) * DE_V6_CTL_STRIDE], 8); out[k] += v; }      // region statistics
+        for (int k = 128; k < n && k < 192; ++k) { uint64_t v; memcpy(&v, &h[(size_t)(bs::G_DRAIN + k - 128) * DE_V6_CTL_STRIDE], 8); out[k] += v; }      // the drain's population histogram
     }
     return DE_OK;
 }

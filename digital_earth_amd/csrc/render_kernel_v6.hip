@@ -76,7 +76,8 @@ static_assert(DE_V6_WAVES <= 31, "the lap tag of a ring cell has five bits: one 
 // 1-3 (64-bit, 100 MHz real-time counter; every build): the launch's first workgroup start, the first wave that found the work counter exhausted, the last wave's exit
 // — the launch's DRAIN, the time its last paths take once nothing is left to start, is what separates a rank's 1/N share from 1/N of the frame (de_last_launch_phases)
 // G_WORKX + x: the work counter of image band x (see run_primary: one band per XCD)
-enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORKX = 8 + 64 + 64, G_WORDS = 8 + 64 + 64 + 8 };
+// G_DRAIN + k (STATS builds): the launch's drain in 0.25 ms buckets since G_T_EXHAUSTED — [k] paths alive in the workgroups that are still resident at the start of bucket k, [32 + k] those workgroups
+enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORKX = 8 + 64 + 64, G_DRAIN = 8 + 64 + 64 + 8, G_WORDS = 8 + 64 + 64 + 8 + 64 };
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
 // 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
 // region statistics (G_STAT2 + k; STATS builds only): where a wave's time goes and how many lanes the region's vector code runs for.  Per loop stage q
@@ -338,6 +339,21 @@ struct Wave {
         }
     }
 
+    // STATS builds: the workgroup's population once the work items are gone, sampled by whichever wave passes the scheduler first in each 0.25 ms bucket
+    DE_DEV void drain_sample(uint32_t live) {
+        if (lane_id() != 0) return;
+        const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (now < t0) return;
+        const unsigned long long bb = (now - t0) / 25000ull + 1ull;
+        const uint32_t b = bb < 32ull ? (uint32_t)bb : 32u;
+        const uint32_t old = __hip_atomic_fetch_max(cw + 17, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (uint32_t k = old; k < b; ++k) {
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.ctl + (G_DRAIN + k) * DE_V6_CTL_STRIDE), (unsigned long long)live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(A.ctl + (G_DRAIN + 32u + k) * DE_V6_CTL_STRIDE), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
     // ---- the scheduler: which stage this wave runs next — a queue id, Q_PRIMARY, or Q_EXIT
     DE_DEV int schedule() {
         uint32_t idle = 0;
@@ -359,6 +375,7 @@ struct Wave {
             // deepens) unless nothing else is there
             if (best_q >= 0 && best < (int)A.enter_min && idle < 4u) best_q = -1;
             const int free_slots = __builtin_amdgcn_readlane(ready, Q_FREE);
+            if (STATS && !primary_left) drain_sample((uint32_t)((int)DE_V6_P - free_slots));
             // new paths as soon as a wave-load of slots is free: the population stays at the pool's size, the rings stay deep
             if (primary_left && free_slots >= 64) return Q_PRIMARY;
             if (best_q >= 0) { stat(ST_ENTRIES, 1); return best_q; }

@@ -32,7 +32,8 @@ def main():
     r.accumulate(a.spp); r.synchronize()
     r.reset_framebuffer(); r.synchronize()
     t0 = time.perf_counter(); r.accumulate(a.spp); r.synchronize(); ms = (time.perf_counter() - t0) * 1e3
-    st = r.v6_stats(128)
+    st = r.v6_stats(192)
+    phases = r.last_launch_phases()
     if not any(st):
         raise SystemExit("no statistics: run with DE_V6_STATS=1")
     name = "%dx%d, %d spp, %s%s%s" % (a.width, a.height, a.spp, a.preset or "default camera", ", cloud-heavy maps" if a.cloud_heavy else "", ", 1/%d share" % a.world if a.world > 1 else "")
@@ -72,6 +73,20 @@ def main():
     L.append("| new paths | ring work | %.2f %% | - | %.0f ticks per pass |" % (100.0 * r2[60] / max(ticks, 1), r2[60] / max(r2[61], 1)))
     L += ["", "Time-weighted active lanes over all regions: **%.3f** of 64 (regions without vector work count as 0 lanes; divergence INSIDE a step body or a stage body is not seen here — "
           "the hardware counter of the same workload is the product of the two)." % (lane_ticks / 64.0 / max(ticks, 1)), ""]
+    # the drain: population of the resident workgroups in 0.25 ms buckets after the work counter ran out
+    dr = st[128:192]
+    if any(dr):
+        n_wg = max(dr[32], 1)
+        L += ["## Drain (the launch's own clock: %.2f ms in all, %.2f ms after the last work item was handed out)" % phases, "",
+              "Sampled by the first wave of each workgroup that passes the scheduler in a 0.25 ms bucket.  `slot-time held` = resident workgroups x bucket; `slot-time needed` = paths alive / %d slots x bucket: what "
+              "the same paths would hold if they sat in full workgroups." % 1120, "",
+              "| ms after exhaustion | resident workgroups | paths alive | per resident workgroup | fill |", "|---|---|---|---|---|"]
+        held = need = 0.0
+        for k in range(32):
+            if dr[32 + k] == 0: continue
+            L.append("| %.2f%s | %d | %d | %.0f | %.3f |" % (0.25 * k, "+" if k == 31 else "", dr[32 + k], dr[k], dr[k] / dr[32 + k], dr[k] / dr[32 + k] / 1120.0))
+            held += 0.25 * dr[32 + k]; need += 0.25 * dr[k] / 1120.0
+        L += ["", "Workgroup-slot time held during the drain: **%.2f ms x %d slots**; needed at full workgroups: %.2f ms x %d slots." % (held / n_wg, n_wg, need / n_wg, n_wg), ""]
     text = "\n".join(L)
     print(text)
     if a.out:
