@@ -92,7 +92,7 @@ int de_destroy(de_ctx* c) {
     legacy_destroy(c);
 #endif
     for (auto& S : c->v6s) {
-        if (S.cold) hipFree(S.cold); if (S.ctl) hipFree(S.ctl); if (S.d_args) hipFree(S.d_args);
+        if (S.cold) hipFree(S.cold); if (S.ctl) hipFree(S.ctl); if (S.d_args) hipFree(S.d_args); if (S.pool[0]) hipFree(S.pool[0]); if (S.pool[1]) hipFree(S.pool[1]);
         if (S.h_status) hipHostFree(S.h_status);
     }
     for (int i = 0; i < DE_MAX_SLOTS; ++i) {
@@ -327,7 +327,7 @@ int de_get_memory_use(de_ctx* c, uint64_t* queue_bytes) {
 #ifdef DE_LEGACY_VARIANTS
     n += legacy_memory_use(c);
 #endif
-    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold);      // the per-CU scheduler: 37 MB per launch slot, whatever the call
+    for (auto& S : c->v6s) if (S.cold) n += (uint64_t)S.n_wg * DE_V6_P * sizeof(wf::Cold) + ((uint64_t)S.pool_cap[0] + S.pool_cap[1]) * DE_V6_POOL_ENTRY_BYTES;      // the per-CU scheduler: 37 MB per launch slot, whatever the call
     *queue_bytes = n;
     return DE_OK;
 }
@@ -515,6 +515,8 @@ int de_get_tuning(de_ctx* c, de_tuning* t) {
     for (int k = 0; k < 3; ++k) { t->v6_service_area[k] = c->v6_svc_area[k]; t->v6_service_lanes[k] = c->v6_svc[k]; }
     t->v6_yield_max = c->v6_yield; t->v6_elsewhere_min = c->v6_elsewhere; t->v6_retry = c->v6_retry; t->v6_enter_min = c->v6_enter_min;
     t->v6_flat_min = c->v6_flat_min; t->v6_flat_again = c->v6_flat_again; t->v6_bands = c->v6_bands; t->v6_stats = c->v6_stats;
+    t->v6_tail_levels = c->v6_tail_levels; t->v6_tail_min_paths = c->v6_tail_min_paths;
+    for (int k = 0; k < 2; ++k) { t->v6_tail_export[k] = c->v6_tail_export[k]; t->v6_tail_grid[k] = c->v6_tail_grid[k]; }
     t->v2_pend = c->tune_pend; t->v2_heavy = c->tune_heavy; t->v2_b = c->tune_b; t->v2_gas = c->tune_gas; t->v2_chunk = c->tune_chunk;
     t->v2_waves_per_cu = c->tune_wpc; t->v2_max_spp = c->tune_max_spp;
     t->trace = c->trace ? 1 : 0;
@@ -526,6 +528,8 @@ int de_set_tuning(de_ctx* c, const de_tuning* t) {
     if (t->launch_slots < 1 || t->launch_slots > DE_MAX_SLOTS || t->big_launch_slots < 1 || t->big_launch_slots > DE_MAX_SLOTS) return fail(DE_ERR_INVALID, "launch slots must be 1..8");
     if (t->v2_chunk < 1 || t->v2_waves_per_cu < 1 || t->v2_waves_per_cu > 20 || t->v6_flat_again < 1 || t->v6_min_paths < 64) return fail(DE_ERR_INVALID, "tuning value out of range");
     for (int k = 0; k < 3; ++k) if (t->v6_service_lanes[k] < 1 || t->v6_service_lanes[k] > 64 || t->v6_service_area[k] < 0) return fail(DE_ERR_INVALID, "service thresholds out of range");
+    if (t->v6_tail_levels < 0 || t->v6_tail_levels > 2) return fail(DE_ERR_INVALID, "v6_tail_levels must be 0..2");
+    for (int k = 0; k < 2; ++k) if (t->v6_tail_export[k] < 1 || t->v6_tail_export[k] > 1024 || t->v6_tail_grid[k] < 1 || t->v6_tail_grid[k] > 4096) return fail(DE_ERR_INVALID, "tail settings out of range");
     int rc = de_set_kernel_variant(c, t->kernel_variant);
     if (rc) return rc;
     if (t->launch_slots != c->n_slots || t->big_launch_slots != c->big_slots) { rc = de_set_launch_slots(c, t->launch_slots, t->big_launch_slots); if (rc) return rc; }
@@ -533,6 +537,8 @@ int de_set_tuning(de_ctx* c, const de_tuning* t) {
     for (int k = 0; k < 3; ++k) { c->v6_svc_area[k] = t->v6_service_area[k]; c->v6_svc[k] = t->v6_service_lanes[k]; }
     c->v6_yield = t->v6_yield_max; c->v6_elsewhere = t->v6_elsewhere_min; c->v6_retry = t->v6_retry; c->v6_enter_min = t->v6_enter_min;
     c->v6_flat_min = t->v6_flat_min; c->v6_flat_again = t->v6_flat_again; c->v6_bands = t->v6_bands == 8 ? 8 : 1; c->v6_stats = t->v6_stats;
+    c->v6_tail_levels = t->v6_tail_levels; c->v6_tail_min_paths = t->v6_tail_min_paths;
+    for (int k = 0; k < 2; ++k) { c->v6_tail_export[k] = t->v6_tail_export[k]; c->v6_tail_grid[k] = t->v6_tail_grid[k]; }
     c->tune_pend = t->v2_pend; c->tune_heavy = t->v2_heavy; c->tune_b = t->v2_b; c->tune_gas = t->v2_gas; c->tune_chunk = t->v2_chunk;
     c->tune_wpc = t->v2_waves_per_cu; c->tune_max_spp = t->v2_max_spp;
     c->trace = t->trace != 0;

@@ -123,7 +123,11 @@ struct de_ctx {
         RenderArgs* d_args = nullptr;
         uint32_t* h_status = nullptr;     // pinned, device-visible: the kernel's abort code
         uint32_t n_wg = 0;
+        uint4* pool[2] = {nullptr, nullptr};      // the tail's pools (render_kernel_v6.hip: "The tail"): level k exports to pool[k & 1]
+        uint32_t pool_cap[2] = {0, 0};            // entries
     } v6s[DE_MAX_SLOTS];
+    int v6_tail_levels = 1, v6_tail_export[2] = {128, 96}, v6_tail_grid[2] = {64, 8};
+    uint32_t v6_tail_min_paths = 4u << 20;
     int v6_bands = 8;                // work counters of a launch: 8 = one band of the image per XCD, 1 = one for the whole launch (render_kernel_v6.hip: run_primary)
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v6_svc[3] = {24, 24, 20};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)

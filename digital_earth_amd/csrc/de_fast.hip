@@ -10,8 +10,13 @@
 #include "render_kernel_v6.hip"
 
 // launched by de_launch.h: launch_v6 (the control words and RenderArgs are initialised there, by the contract unit's v6_init_kernel)
-hipError_t de_fast_launch_v6(const bs::Args& A, const FrameConsts* fc, dim3 grid, dim3 block, hipStream_t stream, bool clamp) {
-    if (clamp) hipLaunchKernelGGL((v6_kernel<true, false>), grid, block, 0, stream, A, fc);
-    else hipLaunchKernelGGL((v6_kernel<false, false>), grid, block, 0, stream, A, fc);
+hipError_t de_fast_launch_v6(const bs::Args& A, const FrameConsts* fc, dim3 grid, dim3 block, hipStream_t stream, bool clamp, bool tail) {
+    if (tail) {
+        if (clamp) hipLaunchKernelGGL((v6_kernel<true, false, true>), grid, block, 0, stream, A, fc);
+        else hipLaunchKernelGGL((v6_kernel<false, false, true>), grid, block, 0, stream, A, fc);
+    } else {
+        if (clamp) hipLaunchKernelGGL((v6_kernel<true, false, false>), grid, block, 0, stream, A, fc);
+        else hipLaunchKernelGGL((v6_kernel<false, false, false>), grid, block, 0, stream, A, fc);
+    }
     return hipGetLastError();
 }

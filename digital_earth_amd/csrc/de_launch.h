@@ -178,6 +178,18 @@ void legacy_note_abort(de_ctx* c);
 int v6_reserve(de_ctx* c, int idx, hipStream_t stream) {
     de_ctx::V6State& S = c->v6s[idx];
     const uint32_t n_wg = (uint32_t)c->n_cus * DE_V6_WG_PER_CU;
+    // the tail's pools: level k exports at most (workgroups of level k) x v6_tail_export[k] records (render_kernel_v6.hip: "The tail")
+    uint32_t want[2] = {0u, 0u};
+    if (c->v6_tail_levels >= 1) want[0] = n_wg * (uint32_t)c->v6_tail_export[0];
+    if (c->v6_tail_levels >= 2) want[1] = std::min((uint32_t)c->v6_tail_grid[0], n_wg) * (uint32_t)c->v6_tail_export[1];
+    for (int k = 0; k < 2; ++k) {
+        if (S.pool_cap[k] >= want[k]) continue;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (S.pool[k]) hipFree(S.pool[k]);
+        S.pool[k] = nullptr; S.pool_cap[k] = 0;
+        if (hipMalloc(&S.pool[k], (size_t)want[k] * DE_V6_POOL_ENTRY_BYTES + 64u) != hipSuccess) { (void)hipGetLastError(); S.pool[k] = nullptr; return fail(DE_ERR_NOMEM, "no room for the tail pool of a render_kernel_v6 launch slot"); }
+        S.pool_cap[k] = want[k];
+    }
     if (S.cold && S.ctl && S.d_args && S.h_status && S.n_wg == n_wg) return DE_OK;      // all four or none: a slot whose allocation failed half way is completed (or fails again) here
     HIP_TRY(hipStreamSynchronize(stream));
     if (S.cold) hipFree(S.cold);
@@ -193,7 +205,7 @@ int v6_reserve(de_ctx* c, int idx, hipStream_t stream) {
     return DE_OK;
 }
 }  // namespace
-hipError_t de_fast_launch_v6(const bs::Args& A, const FrameConsts* fc, dim3 grid, dim3 block, hipStream_t stream, bool clamp);      // de_fast.hip
+hipError_t de_fast_launch_v6(const bs::Args& A, const FrameConsts* fc, dim3 grid, dim3 block, hipStream_t stream, bool clamp, bool tail);      // de_fast.hip
 namespace {
 hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx) {
     de_ctx::V6State& S = c->v6s[idx];
@@ -213,10 +225,27 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     // DE_V6_WG_PER_CU workgroups per CU; a small launch: one per wave-load of new paths per wave (a workgroup's waves start 64 at a time)
     const unsigned by_work = (unsigned)((A.n_items + 64u * DE_V6_WAVES - 1u) / (64u * DE_V6_WAVES));
     dim3 grid(by_work < S.n_wg ? (by_work ? by_work : 1u) : S.n_wg), block(64 * DE_V6_WAVES);
-    if ((c->p.flags & DE_FLAG_FAST_MATH) != 0u) return de_fast_launch_v6(A, a.fc, grid, block, stream, clamp);      // de_fast.hip: the same kernel on the hardware's transcendentals (opt-in, not bit-reproducible)
-    if (c->v6_stats && !clamp) hipLaunchKernelGGL((v6_kernel<false, true>), grid, block, 0, stream, A, a.fc);
-    else if (clamp) hipLaunchKernelGGL((v6_kernel<true, false>), grid, block, 0, stream, A, a.fc);
-    else hipLaunchKernelGGL((v6_kernel<false, false>), grid, block, 0, stream, A, a.fc);
+    // The frame's chain (render_kernel_v6.hip: "The tail"): a launch that fills the GPU exports its workgroups' last paths instead of waiting for
+    // them, and up to two small launches of the same kernel — on this stream: the pool is complete when they start — finish them.
+    const int levels = A.n_items >= c->v6_tail_min_paths ? c->v6_tail_levels : 0;      // (4 Mi paths by default: launches that fill the GPU several times over)
+    const bool fast = (c->p.flags & DE_FLAG_FAST_MATH) != 0u;
+    for (int l = 0; l <= levels; ++l) {
+        A.level = (uint32_t)l;
+        A.export_at = l < levels ? (uint32_t)c->v6_tail_export[l] : 0u;
+        A.pool_out = l < levels ? S.pool[l & 1] : nullptr; A.cap_out = l < levels ? S.pool_cap[l & 1] : 0u;
+        A.pool_in = l > 0 ? S.pool[(l - 1) & 1] : nullptr; A.cap_in = l > 0 ? S.pool_cap[(l - 1) & 1] : 0u;
+        const dim3 g = l == 0 ? grid : dim3(std::min((unsigned)c->v6_tail_grid[l - 1], (unsigned)S.n_wg));      // the cold records are per workgroup slot: at most n_wg
+        if (fast) { hipError_t e2 = de_fast_launch_v6(A, a.fc, g, block, stream, clamp, l > 0); if (e2 != hipSuccess) return e2; continue; }      // de_fast.hip: the same kernel on the hardware's transcendentals (opt-in, not bit-reproducible)
+        if (l == 0) {
+            if (c->v6_stats && !clamp) hipLaunchKernelGGL((v6_kernel<false, true, false>), g, block, 0, stream, A, a.fc);
+            else if (clamp) hipLaunchKernelGGL((v6_kernel<true, false, false>), g, block, 0, stream, A, a.fc);
+            else hipLaunchKernelGGL((v6_kernel<false, false, false>), g, block, 0, stream, A, a.fc);
+        } else {
+            if (c->v6_stats && !clamp) hipLaunchKernelGGL((v6_kernel<false, true, true>), g, block, 0, stream, A, a.fc);
+            else if (clamp) hipLaunchKernelGGL((v6_kernel<true, false, true>), g, block, 0, stream, A, a.fc);
+            else hipLaunchKernelGGL((v6_kernel<false, false, true>), g, block, 0, stream, A, a.fc);
+        }
+    }
     return hipGetLastError();
 }
 // Did a persistent launch leave on its abort word?  The word is host-visible pinned memory written by the kernel when it gives up; what has
@@ -229,7 +258,7 @@ void note_abort(de_ctx* c) {
             const uint32_t code = S.h_status[0];
             S.h_status[0] = 0u;
             c->frame_invalid = true;
-            c->invalid_msg = std::string("render_kernel_v6 left on its abort word (") + (code == bs::ERR_ENTRY_TIMEOUT ? "a ring entry was never stored" : code == bs::ERR_CELL_BUSY_TIMEOUT ? "a ring cell was never emptied" : "idle watchdog: work was lost") + "): the frame is invalid until de_reset";
+            c->invalid_msg = std::string("render_kernel_v6 left on its abort word (") + (code == bs::ERR_ENTRY_TIMEOUT ? "a ring entry was never stored" : code == bs::ERR_CELL_BUSY_TIMEOUT ? "a ring cell was never emptied" : code == bs::ERR_POOL_FULL ? "the tail pool overflowed" : "idle watchdog: work was lost") + "): the frame is invalid until de_reset";
         }
     }
 #ifdef DE_LEGACY_VARIANTS

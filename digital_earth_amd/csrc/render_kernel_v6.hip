@@ -35,7 +35,7 @@ using wf::Path;
 using wf::NQ;
 using wf::Q_ST; using wf::Q_GAS; using wf::Q_CLOUD; using wf::Q_EVENT; using wf::Q_SURF; using wf::Q_SCFIN; using wf::Q_SURFFIN;
 
-enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2 };
+enum { Q_FREE = NQ, NR = NQ + 1, Q_PRIMARY = NQ + 1, Q_EXIT = NQ + 2, Q_EXPORT = NQ + 3 };
 // Geometry.  The stage functions are separate (non-inlined) device functions: each gets the registers ITS body needs (36 ... 78, as the
 // stage kernels of render_kernel_v3.hip) instead of the 128 + spills the register allocator gives the seven stages inlined into one
 // function, so the kernel fits 80 VGPRs = 6 waves per SIMD.  24 waves per CU = two workgroups of twelve waves, 80 KB of LDS each.
@@ -77,7 +77,8 @@ static_assert(DE_V6_WAVES <= 31, "the lap tag of a ring cell has five bits: one 
 // — the launch's DRAIN, the time its last paths take once nothing is left to start, is what separates a rank's 1/N share from 1/N of the frame (de_last_launch_phases)
 // G_WORKX + x: the work counter of image band x (see run_primary: one band per XCD)
 // G_DRAIN + k (STATS builds): the launch's drain in 0.25 ms buckets since G_T_EXHAUSTED — [k] paths alive in the workgroups that are still resident at the start of bucket k, [32 + k] those workgroups
-enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORKX = 8 + 64 + 64, G_DRAIN = 8 + 64 + 64 + 8, G_WORDS = 8 + 64 + 64 + 8 + 64 };
+enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORKX = 8 + 64 + 64, G_DRAIN = 8 + 64 + 64 + 8, G_POOL = 8 + 64 + 64 + 8 + 64, G_WORDS = 8 + 64 + 64 + 8 + 64 + 8 };
+// G_POOL + 2 l: entries written to the pool that launch level l exports to; G_POOL + 2 l + 1: entries of that pool handed out to level l + 1 (see "The tail" below)
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
 // 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
 // region statistics (G_STAT2 + k; STATS builds only): where a wave's time goes and how many lanes the region's vector code runs for.  Per loop stage q
@@ -88,7 +89,7 @@ enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G
 // pass's ring work (claim, take, record load / store, appends), passes.  The same four for new paths (primary sphere trace included) at 58.
 enum { R_STEP = 0, R_EPI, R_PUSH, R_REFILL, R_YIELD, R_HEAD, R_N };
 enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_DRAIN = 22, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
-enum { ERR_ENTRY_TIMEOUT = 1, ERR_CELL_BUSY_TIMEOUT = 2, ERR_IDLE_WATCHDOG = 3 };
+enum { ERR_ENTRY_TIMEOUT = 1, ERR_CELL_BUSY_TIMEOUT = 2, ERR_IDLE_WATCHDOG = 3, ERR_POOL_FULL = 4 };
 // cell values as the 16-bit stores truncate them (the lap's high bits fall off)
 DE_DEV uint32_t cell_empty(uint32_t lap) { return (lap << 11) | DE_V6_SLOT_MASK; }
 DE_DEV uint32_t cell_full(uint32_t lap, uint32_t slot) { return (lap << 11) | slot; }
@@ -112,8 +113,27 @@ struct Args {
     uint32_t flat_min;          // a straight-line stage is entered with fewer entries than this only when the loop stages' rings are empty (0: off; measured flat)
     uint32_t flat_again;        // a straight-line stage runs a FURTHER pass only when its ring holds at least this many entries (1: until the ring is dry)
     uint32_t bands;             // work counters: 8 = one band of the image per XCD (run_primary), 1 = one counter for the whole launch
+    // the tail (see "The tail" below): this launch's level in the frame's chain, when its workgroups export, and the pools on either side
+    uint32_t level;             // 0: the launch that starts the frame's paths; k > 0: the k-th tail launch — its "new paths" are what level k - 1 exported
+    uint32_t export_at;         // > 0: a workgroup with nothing left to start and at most this many paths alive exports them to pool_out and exits
+    uint4* pool_in; uint4* pool_out;
+    uint32_t cap_in, cap_out;   // entries the pools hold
 };
 template <int... T> struct Targets {};
+
+// The tail.  Once the work counter has run out a workgroup's population decays — BASELINE cfg2: 96 % of the slots 0.5 ms later, 50 % after 1.25 ms, 8 %
+// after 2.25 ms — but its last path ends 3 ... 8 ms later (a 25-vertex cloud path is a chain of ~150 dependent stage passes), and until then the
+// workgroup keeps half a CU's LDS for a handful of paths: 4.15 ms x 512 workgroup slots held per launch where 1.43 would do at full workgroups
+// (profiles/r5_lanes: the drain table), a quarter of a rank's 1/8 share of a frame.  So a launch does not wait for its stragglers: a workgroup with
+// nothing left to start and at most export_at paths alive has its loop stages hand their records back (the yield path: the loop's state is in the
+// record and its cold record), copies every queued record — 56 bytes of LDS, the 64-byte cold record, the ring it waits in — to a pool in HBM and
+// exits; the next launch of the chain (same stream: the pool is complete when it starts) has few workgroups whose "new paths" are the pool's
+// entries, and may export in turn.  A path's arithmetic does not know where it runs: results are unchanged bit for bit.
+struct Pool {
+    uint4 *a, *b, *c, *cold; uint2* d; uint32_t* q;
+    DE_DEV Pool(uint4* base, uint32_t cap) : a(base), b(base + cap), c(base + 2u * cap), cold(base + 3u * cap), d(reinterpret_cast<uint2*>(base + 7u * (size_t)cap)), q(reinterpret_cast<uint32_t*>(base + 7u * (size_t)cap) + 2u * (size_t)cap) {}
+};
+#define DE_V6_POOL_ENTRY_BYTES 124u        // 3 x 16 + 8 (the record) + 64 (its cold record) + 4 (its ring)
 
 // what every stage function needs of the launch: written to LDS once per workgroup, read (wave-uniform) at each stage entry
 struct Cfg {
@@ -128,16 +148,18 @@ struct Cfg {
     uint32_t yield_max, elsewhere_min, retry, enter_min;
     uint32_t flat_min, flat_again;
     uint32_t bands, xcd;        // xcd: the XCD this workgroup runs on (HW_REG_XCC_ID)
+    uint4* pool_in; uint4* pool_out;
+    uint32_t level, export_at, cap_in, cap_out;
 };
-static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 128, "Cfg is copied dword by dword");
+static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 144, "Cfg is copied dword by dword");
 
 __shared__ uint4 s_rec[3u * DE_V6_P];                // the record slots: three 16-byte parts, part-major ...
 __shared__ uint2 s_rec2[DE_V6_P];                    // ... and one of 8 bytes
 __shared__ uint16_t s_rings[(NQ + 1) * DE_V6_CAP];   // NR rings of slot numbers
-__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16
+__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16, drain statistics at 17, "exporting" at 18
 __shared__ float s_node_val[64];
 __shared__ unsigned long long s_stats[64];
-__shared__ uint32_t s_cfg[32];
+__shared__ uint32_t s_cfg[36];
 
 DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -376,6 +398,27 @@ struct Wave {
             if (best_q >= 0 && best < (int)A.enter_min && idle < 4u) best_q = -1;
             const int free_slots = __builtin_amdgcn_readlane(ready, Q_FREE);
             if (STATS && !primary_left) drain_sample((uint32_t)((int)DE_V6_P - free_slots));
+            if (A.export_at != 0u && !primary_left) {
+                // the tail: nothing left to start and few paths alive — from here on this workgroup only exports (see "The tail")
+                const uint32_t live = DE_V6_P - (uint32_t)free_slots;
+                // (only once EVERY wave of the workgroup knows that nothing is left to start — a wave may hold the rest of a 256-item claim while it works in a
+                // stage: from then on the population can only fall, so a workgroup exports at most export_at records and the pool cannot overflow)
+                uint32_t two = 0;
+                if (lane_id() < 2) two = ld_wg(cw + 18 + lane_id());
+                bool exporting = __builtin_amdgcn_readlane((int)two, 0) != 0;
+                const bool starters = __builtin_amdgcn_readlane((int)two, 1) != 0;
+                if (!exporting && !starters && live != 0u && live <= A.export_at) {
+                    if (lane_id() == 0) __hip_atomic_store(cw + 18, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    exporting = true;
+                }
+                if (exporting) {
+                    if (best > 0) return Q_EXPORT;
+                    if (free_slots == (int)DE_V6_P) return Q_EXIT;
+                    if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
+                    __builtin_amdgcn_s_sleep(8);      // records are still in the lanes of a loop stage (they come back at its next dry service) or in a straight-line pass
+                    continue;
+                }
+            }
             // new paths as soon as a wave-load of slots is free: the population stays at the pool's size, the rings stay deep
             if (primary_left && free_slots >= 64) return Q_PRIMARY;
             if (best_q >= 0) { stat(ST_ENTRIES, 1); return best_q; }
@@ -440,7 +483,8 @@ struct Wave {
                         // Nothing to refill from, a few long records left, and other work waits: hand the records back — the loop's
                         // state goes to the spare words of their cold records — so that they fill the idle lanes of another wave of this
                         // stage instead of running here at a fraction of the wave (cloud segments have a heavy tail)
-                        if (nb > 0 && nb <= (int)A.yield_max && work_elsewhere(Q)) {
+                        // (or the workgroup is exporting its last paths — "The tail": whatever runs here goes back to the ring, from there to the pool)
+                        if (nb > 0 && ((nb <= (int)A.yield_max && work_elsewhere(Q)) || (A.export_at != 0u && uni(ld_wg(cw + 18)) != 0u))) {
                             if (busy) {
                                 st.suspend(p, cold + slot);
                                 p.meta |= 0x80000000u;
@@ -500,6 +544,71 @@ struct Wave {
         return __ballot(ready >= (int)A.elsewhere_min) != 0ull;
     }
 
+    // ---- the tail: every queued record of ring Q to the pool (its slot goes home); the records in the lanes of the loop stages follow when those yield
+    template <int Q>
+    DE_DEV void export_ring(const Pool& pool) {
+        for (;;) {
+            uint32_t first = 0;
+            const uint32_t n = claim(Q, 1u, 64u, &first);
+            if (n == 0u) break;
+            const bool active = (uint32_t)lane_id() < n;
+            uint32_t slot = 0;
+            if (active) slot = take(Q, first + (uint32_t)lane_id());
+            if (__ballot(active && slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); break; }
+            acquire_wg();
+            uint32_t base = 0;
+            if (lane_id() == 0) base = __hip_atomic_fetch_add(A.ctl + (G_POOL + 2u * A.level) * DE_V6_CTL_STRIDE, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base = uni(base);
+            if (base + n > A.cap_out) { raise(ERR_POOL_FULL); break; }      // cannot happen: a workgroup exports at most export_at records, the pool holds that many per workgroup
+            if (active) {
+                const uint32_t i = base + (uint32_t)lane_id();
+                pool.a[i] = rec[slot]; pool.b[i] = rec[DE_V6_P + slot]; pool.c[i] = rec[2u * DE_V6_P + slot]; pool.d[i] = s_rec2[slot];
+                const uint4* cs = reinterpret_cast<const uint4*>(cold + slot);
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) pool.cold[(size_t)k * A.cap_out + i] = cs[k];
+                pool.q[i] = (uint32_t)Q;
+            }
+            push<Q_FREE>(slot, active);
+        }
+    }
+    template <int... QS>
+    DE_DEV void run_export(Targets<QS...>) {
+        const Pool pool(A.pool_out, A.cap_out);
+        (export_ring<QS>(pool), ...);
+    }
+    // ---- a tail launch's "new paths": up to 64 entries of the pool the previous level exported, each to the ring it waited in
+    DE_DEV void run_import() {
+        uint32_t first = 0;
+        if (claim(Q_FREE, 64u, 64u, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return; }
+        uint32_t slot = take(Q_FREE, first + (uint32_t)lane_id());
+        if (__ballot(slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return; }
+        acquire_wg();
+        uint32_t w = 0, total = 0;
+        if (lane_id() == 0) {
+            w = __hip_atomic_fetch_add(A.ctl + (G_POOL + 2u * (A.level - 1u) + 1u) * DE_V6_CTL_STRIDE, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total = __hip_atomic_load(A.ctl + (G_POOL + 2u * (A.level - 1u)) * DE_V6_CTL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // final: the exporting launch has ended
+        }
+        w = uni(w); total = min(uni(total), A.cap_in);
+        const uint32_t n = w < total ? min(64u, total - w) : 0u;
+        const bool active = (uint32_t)lane_id() < n;
+        uint32_t q = 0xffu;
+        if (active) {
+            const Pool pool(A.pool_in, A.cap_in);
+            const uint32_t i = w + (uint32_t)lane_id();
+            rec[slot] = pool.a[i]; rec[DE_V6_P + slot] = pool.b[i]; rec[2u * DE_V6_P + slot] = pool.c[i]; s_rec2[slot] = pool.d[i];
+            uint4* cd = reinterpret_cast<uint4*>(cold + slot);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) cd[k] = pool.cold[(size_t)k * A.cap_in + i];
+            q = pool.q[i];
+        }
+        stat(ST_RECS + NQ, n);
+        release_wg();
+        push<Q_ST>(slot, q == (uint32_t)Q_ST); push<Q_GAS>(slot, q == (uint32_t)Q_GAS); push<Q_CLOUD>(slot, q == (uint32_t)Q_CLOUD); push<Q_EVENT>(slot, q == (uint32_t)Q_EVENT);
+        push<Q_SURF>(slot, q == (uint32_t)Q_SURF); push<Q_SCFIN>(slot, q == (uint32_t)Q_SCFIN); push<Q_SURFFIN>(slot, q == (uint32_t)Q_SURFFIN);
+        push<Q_FREE>(slot, !active);      // the slots claimed beyond the pool's end go home
+        if (n < 64u) primary_left = false;
+    }
+
     // ---- a straight-line stage: up to 64 slots per pass, one record per lane, written back in place
     template <int Q, typename Body, int... TARGETS>
     DE_DEV void run_flat(Body body, Targets<TARGETS...>) {
@@ -551,6 +660,7 @@ struct Wave {
             for (;;) {
                 if (w_tries >= nb) {
                     primary_left = false;
+                    if (lane_id() == 0) add_wg(cw + 19, 0xffffffffu);      // one wave fewer that may still start paths (see schedule: the tail)
                     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                     if (lane_id() == 0) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (STATS) t_drain = now;
@@ -667,7 +777,22 @@ DE_V6_STAGE v6_stage_surffin(bool primary_left) {
     W.template run_flat<Q_SURFFIN>([&](Path& p, const ColdAt& cold) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
 }
 
-template <bool CLAMP, bool STATS>
+// TAIL = false: the launch that starts a frame's paths (level 0).  TAIL = true: a tail launch — the same scheduler and stage functions, its new
+// paths are the previous level's pool (its own kernel name, so that a kernel trace tells the two apart).
+// the tail's two record movers, out of line like the stages (inlined they cost the kernel's own body — the scheduler and the new paths — its registers)
+DE_V6_STAGE v6_stage_export(bool primary_left) {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    W.run_export(Targets<Q_ST, Q_GAS, Q_CLOUD, Q_EVENT, Q_SURF, Q_SCFIN, Q_SURFFIN>{});
+}
+template <bool CLAMP, bool STATS> __device__ __attribute__((noinline)) bool v6_stage_import() {      // false: the pool is exhausted
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
+    W.run_import();
+    return W.primary_left;
+}
+
+template <bool CLAMP, bool STATS, bool TAIL>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64 * DE_V6_WAVES, 64 * DE_V6_WAVES), amdgpu_waves_per_eu(DE_V6_WPE, DE_V6_WPE)))
 v6_kernel(bs::Args A, const FrameConsts* fcp) {
     using namespace bs;
@@ -675,7 +800,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         const uint32_t q = i / DE_V6_CAP, k = i % DE_V6_CAP;
         s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? cell_full(0u, k) : cell_empty(0u));
     }
-    if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : 0u;
+    if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : (threadIdx.x == 19u ? (uint32_t)DE_V6_WAVES : 0u);
     if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; s_stats[threadIdx.x] = 0ull; }
     if (threadIdx.x == 0u) {
         Cfg c;
@@ -685,12 +810,13 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         c.svc_area[0] = A.svc_area[0]; c.svc_area[1] = A.svc_area[1]; c.svc_area[2] = A.svc_area[2];
         c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.flat_min = A.flat_min; c.flat_again = A.flat_again;
         c.bands = A.bands == 8u ? 8u : 1u;
+        c.pool_in = A.pool_in; c.pool_out = A.pool_out; c.level = A.level; c.export_at = A.export_at; c.cap_in = A.cap_in; c.cap_out = A.cap_out;
         { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); c.xcd = xcc & 7u; }
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];
     }
     __syncthreads();
-    if (threadIdx.x == 0u) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_START * DE_V6_CTL_STRIDE), (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!TAIL && threadIdx.x == 0u) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_START * DE_V6_CTL_STRIDE), (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
     W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -711,10 +837,19 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         case Q_SURF: v6_stage_surf<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURF>(); break;
         case Q_SCFIN: v6_stage_scfin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SCFIN>(); break;
         case Q_SURFFIN: v6_stage_surffin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURFFIN>(); break;
+        case Q_EXPORT: v6_stage_export<CLAMP, STATS>(W.primary_left); W.template mark<-1>(); break;
         default: {
-            const RenderArgs& a = *wf::opaque_ptr(W.A.ra);
-            const FrameConsts& fc = *wf::opaque_ptr(W.A.fc);
-            W.run_primary(a, fc);
+            if (TAIL) {
+                if (!v6_stage_import<CLAMP, STATS>()) {
+                    W.primary_left = false;
+                    if (lane_id() == 0) add_wg(s_cw + 19, 0xffffffffu);
+                    if (STATS) W.t_drain = __builtin_amdgcn_s_memrealtime();
+                }
+            } else {
+                const RenderArgs& a = *wf::opaque_ptr(W.A.ra);
+                const FrameConsts& fc = *wf::opaque_ptr(W.A.fc);
+                W.run_primary(a, fc);
+            }
             W.template mark<7>();
         } break;
         }

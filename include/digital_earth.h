@@ -253,6 +253,13 @@ typedef struct de_tuning {
     int32_t v6_service_lanes[3];      /* ... idle lanes at which it does (the rule of round 4) */
     int32_t v6_yield_max, v6_elsewhere_min, v6_retry, v6_enter_min, v6_flat_min, v6_flat_again;   /* render_kernel_v6.hip: bs::Args */
     int32_t v6_bands;                 /* 8: one work counter per XCD, each over its own band of the launch's tiles (default); 1: one counter */
+    int32_t v6_tail_levels;           /* 0: one launch per call.  1, 2: a launch does not wait for its last paths — a workgroup with nothing left to start and few paths alive
+                                         exports them to a pool in HBM and exits, and that many further (small) launches of the same kernel finish them (render_kernel_v6.hip:
+                                         "The tail").  Same bits; applies to launches that fill the GPU */
+    int32_t v6_tail_export[2];        /* level k exports when at most this many paths are alive in the workgroup (1 .. 1024) */
+    uint32_t v6_tail_min_paths;       /* ... and start at least this many paths (default 4 Mi: below that the tail launch's latency — the chain of a frame rendered alone ends ~1 ms
+                                         later — outweighs the workgroup slots it frees; the interactive one-sample frame stays one launch) */
+    int32_t v6_tail_grid[2];          /* workgroups of tail launch k + 1 (they must hold what level k can export: grid x 1120 >= workgroups of level k x v6_tail_export[k]) */
     int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
     int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */
     int32_t trace;                    /* 1: print what each call ran to stderr */

@@ -45,15 +45,20 @@ def test_block_scheduler_matches_the_oracle(Renderer, lut_arrays, preset):
     assert got.max() > 0
 
 
-@pytest.mark.parametrize("yield_max,svc,area,retry,elsewhere,enter_min,flat_again,bands",
-                         [(0, 16, 0, 6, 48, 0, 1, 1), (63, 1, 1, 1, 1, 0, 1, 8), (63, 48, 5000, 2, 1, 0, 64, 8), (32, 8, 0, 12, 200, 64, 16, 1), (56, 63, 400, 1, 16, 32, 32, 8)])
-def test_block_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, yield_max, svc, area, retry, elsewhere, enter_min, flat_again, bands):
+@pytest.mark.parametrize("yield_max,svc,area,retry,elsewhere,enter_min,flat_again,bands,tail",
+                         [(0, 16, 0, 6, 48, 0, 1, 1, (1, 96, 64)), (63, 1, 1, 1, 1, 0, 1, 8, (2, 300, 64)), (63, 48, 5000, 2, 1, 0, 64, 8, (1, 8, 16)), (32, 8, 0, 12, 200, 64, 16, 1, (0, 96, 64)),
+                          (56, 63, 400, 1, 16, 32, 32, 8, (2, 96, 64))])
+def test_block_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, yield_max, svc, area, retry, elsewhere, enter_min, flat_again, bands, tail):
     """No yields at all; a wave that hands its records back whenever its ring is dry and services after every trip with an idle lane
     (each record is suspended and resumed many times); services by idle lane-trips (the shipped rule: area > 0) at both extremes and by
     idle lanes (round 4's rule: area = 0); further straight-line passes from 1 / 16 / 32 / 64 entries; one work counter or one per XCD; a
     scheduler that leaves shallow rings alone: the frame is the state machine's, bit for bit.  1.4 M paths on 512 workgroups of 1120 slots:
     every slot is reused ~3 times per launch.  (The knobs travel as ONE de_set_tuning call: the Python layer reads these variables, the
-    library reads none.)"""
+    library reads none.)  `tail` = (levels, export threshold, workgroups of the first tail launch): the frame's last paths finished by 0 / 1 / 2
+    further launches from pools in HBM (render_kernel_v6.hip, "The tail"), forced on for these small frames; with yields off (first row) the
+    records in the loop stages' lanes only come back through the export's own yield."""
+    monkeypatch.setenv("DE_V6_TAIL", str(tail[0])); monkeypatch.setenv("DE_V6_TAIL_EXPORT0", str(tail[1])); monkeypatch.setenv("DE_V6_TAIL_GRID0", str(tail[2]))
+    monkeypatch.setenv("DE_V6_TAIL_EXPORT1", "40"); monkeypatch.setenv("DE_V6_TAIL_GRID1", "8"); monkeypatch.setenv("DE_V6_TAIL_MIN_PATHS", "0")
     monkeypatch.setenv("DE_V6_YIELD", str(yield_max)); monkeypatch.setenv("DE_V6_RETRY", str(retry))
     monkeypatch.setenv("DE_V6_ELSEWHERE", str(elsewhere)); monkeypatch.setenv("DE_V6_ENTER_MIN", str(enter_min))
     monkeypatch.setenv("DE_V6_FLAT_AGAIN", str(flat_again)); monkeypatch.setenv("DE_V6_BANDS", str(bands))

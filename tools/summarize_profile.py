@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/prof_<tag>/ directory (tools/profile_gpu.sh) into profiles/<tag>_summary.md + profiles/hbm_traffic.json.
 
-A frame of the bench workload is one de_accumulate(64) call.  With the default variant 4 that is one v6_kernel launch (round 4; kernel
+A frame of the bench workload is one de_accumulate(64) call.  With the default variant 4 that is one v6_kernel launch + its tail launch (round 5; kernel
 variants 2 / 5: one render_kernel_v2 / v5_kernel launch); with the wavefront pipeline (variant 3, and variant 4 until round 4) it is a
 sequence: batches side by side, each = the pipeline's stage kernels for the first vertex rounds (v3_*) + render_kernel_v2 as finisher.
 Counters are therefore summed over ALL render kernels of a run and divided by its number of frames; the frame duration is the busy span
@@ -63,13 +63,13 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
         out.append("* frames in the trace: %d (one de_accumulate(64) call each, displayed after it); first render-kernel start to last render-kernel end, median: **%.2f ms** (min %.2f, max %.2f)"
                    % (len(spans), kernel_ms, min(spans), max(spans)))
         if n_primary: out.append("* a frame = %d batches side by side, each: the wavefront pipeline's stage kernels for the first vertex rounds + render_kernel_v2 as finisher of the surviving paths" % batches)
-        else: out.append("* a frame = one launch of the persistent kernel (the per-CU stage scheduler, render_kernel_v6.hip, unless a kernel variant was forced)")
+        else: out.append("* a frame = one launch of the persistent kernel (the per-CU stage scheduler, render_kernel_v6.hip, unless a kernel variant was forced) + its tail launch (`v6_kernel<.., true>`: 64 workgroups that finish the paths the frame's workgroups exported)")
         rsum = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace if RENDER.search(r["Kernel_Name"])) / 1e6 / max(n_display, 1)
         out.append("* sum of the render kernels' own durations per displayed frame: %.1f ms%s" % (rsum, " (the batches overlap)" if n_primary else " (includes the bench's parity and counting launches)"))
         out.append("")
     else:
         for r in stats:
-            if r["Name"].startswith("void v6_kernel<false, false>") or r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
+            if r["Name"].startswith("void v6_kernel<false, false, false>") or r["Name"].startswith("void render_kernel_v2<false, 0>") or (kernel_ms is None and "ray_march_kernel<false, 0>" in r["Name"]):
                 kernel_ms = float(r["AverageNs"]) / 1e6
     # counters: sum over every render kernel of a pass, per frame of that pass
     pmc, frames_in_pass = defaultdict(float), {}
@@ -91,8 +91,15 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
             vals = [v for v in disp.values()]
             key = next((k for k in vals[0] if k != "k"), None) if vals else None
             mx = max((v.get(key, 0.0) for v in vals), default=0.0)
-            use = [v for v in vals if v.get(key, 0.0) >= 0.5 * mx]                                            # the 64-spp launches
-            nf = len(use)
+            TAIL = re.compile(r"v6_kernel\w*<\w+, \w+, true>")                                                # a tail launch of the frame's chain (render_kernel_v6.hip: "The tail")
+            use, nf, parent_in = [], 0, False
+            for did in sorted(disp, key=lambda x: int(x)):                                                     # --sync-frames: a tail launch follows its frame's launch
+                v = disp[did]
+                if TAIL.search(v["k"]):
+                    if parent_in: use.append(v)
+                    continue
+                parent_in = v.get(key, 0.0) >= 0.5 * mx                                                         # the 64-spp launches
+                if parent_in: use.append(v); nf += 1
         for k in {k for v in use for k in v if k not in ("k", "ms")}: passes_with[k] += 1
         for v in use:
             short = re.sub(r"^void ", "", v["k"]).split("(")[0]
@@ -143,7 +150,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                            "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": lane,
                            "salu_insts_per_launch": means.get("SQ_INSTS_SALU"), "source_sha16": source_sha16(),
                            "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), summed over every render kernel of a frame (one "
-                                   "de_accumulate(64) call: one v6_kernel launch under the default variant); read bytes = 2 x FETCH_SIZE (a request "
+                                   "de_accumulate(64) call: one v6_kernel launch and its tail launch under the default variant); read bytes = 2 x FETCH_SIZE (a request "
                                    "moves a 128-B line and is tallied as 64 B: profiles/r2_fetch_calibration). L2-miss traffic at the fabric: "
                                    "Infinity-Cache hits are included"},
                           f, indent=1)
