@@ -268,9 +268,13 @@ def main():
     for f in frames:
         for _ in range(n_prime):
             step(f)
+            if args.sync_frames:                 # (profiling runs: one call at a time from the first launch on, so that a kernel trace holds no launch that waited behind another call's persistent workgroups)
+                f.r.synchronize()
     barrier()
     for i in range(args.warmup):
         step(frames[i % len(frames)])
+        if args.sync_frames:
+            frames[i % len(frames)].r.synchronize()
     elapsed = timed(args.steps)
     timed_info = frames[(args.steps - 1) % len(frames)].r.last_call_info()      # what the calls of the timed region ran (a lone call may run differently)
     last = frames[(args.steps - 1) % len(frames)]
@@ -423,7 +427,7 @@ def main():
                      "frac_overlapped_frames": (b_sample * my_samples / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": ("de_accumulate(%d): kernel variant %s — %s; "
-                                "kernel_ms = the call's duration (HIP events on its launch slots)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), timed_info["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
+                                "kernel_ms = the call's duration (HIP events on its launch slot: v6_kernel<.., false> — the frame's launch — + v6_kernel<.., true>, its 64-workgroup tail launch, back to back)" % (spp, os.environ.get("DE_KERNEL", "4 (automatic)"), timed_info["kernel"])) if args.integrator == "path_tracer" else "ray_march_kernel<false, 0>", "kernel_ms": avg_kernel_ms, "bytes_per_sample": b_sample,
                      "taps_r8_per_sample": n_r8, "taps_rgb_per_sample": n_rgb,
                      "note": "the path is VALU-issue / divergence bound, not HBM bound (SURVEY §8d): see valu"},
         "valu": {"unit": "see fields", "loop_steps_per_sample": steps_per_sample,

@@ -267,7 +267,7 @@ typedef struct de_tuning {
 int de_get_tuning(de_ctx* ctx, de_tuning* out);
 int de_set_tuning(de_ctx* ctx, const de_tuning* in);
 /* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
- * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 37 MB per
+ * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 37 MB of cold records + 8 MB of tail pool per
  * launch slot whatever the call and is not affected): a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
  * pixel that does not fit runs on the state machine).  0 (default) = automatic: what the device has free minus 8 GB, at most 2^27 paths
  * per batch.  Setting it releases what is held.  profiles/memory_budget.md: throughput against the budget.

@@ -58,7 +58,8 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                 end = max(end or 0, int(r["End_Timestamp"]))
             elif "display_kernel" in r["Kernel_Name"] and start is not None:
                 spans.append((end - start) / 1e6); start = end = None
-        spans = [x for x in spans if x >= 0.5 * max(spans)]
+        med = sorted(spans)[len(spans) // 2]
+        spans = [x for x in spans if 0.5 * med <= x <= 1.5 * med]      # not the priming block (several calls in flight between two displays), not the small parity launches
         kernel_ms = sorted(spans)[len(spans) // 2]        # the first frames of a run also allocate the pipeline's queues
         out.append("* frames in the trace: %d (one de_accumulate(64) call each, displayed after it); first render-kernel start to last render-kernel end, median: **%.2f ms** (min %.2f, max %.2f)"
                    % (len(spans), kernel_ms, min(spans), max(spans)))

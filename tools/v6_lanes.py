@@ -76,11 +76,11 @@ def main():
     # the drain: population of the resident workgroups in 0.25 ms buckets after the work counter ran out
     dr = st[128:192]
     if any(dr):
-        n_wg = max(dr[32], 1)
+        n_wg = 512      # workgroup slots of an MI355X (2 per CU); with the tail chain the first bucket also counts the tail launch's 64 workgroups
         L += ["## Drain (the launch's own clock: %.2f ms in all, %.2f ms after the last work item was handed out)" % phases, "",
               "Sampled by the first wave of each workgroup that passes the scheduler in a 0.25 ms bucket.  `slot-time held` = resident workgroups x bucket; `slot-time needed` = paths alive / %d slots x bucket: what "
               "the same paths would hold if they sat in full workgroups." % 1120, "",
-              "| ms after exhaustion | resident workgroups | paths alive | per resident workgroup | fill |", "|---|---|---|---|---|"]
+              "| ms after exhaustion | resident workgroups (frame launch + tail launch) | paths alive in them | per resident workgroup | fill |", "|---|---|---|---|---|"]
         held = need = 0.0
         for k in range(32):
             if dr[32 + k] == 0: continue
