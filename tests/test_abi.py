@@ -41,6 +41,31 @@ def test_struct_layouts_match_header():
     assert _native.DeParams.flags.offset == 84 and _native.DeParams.selected_crf.offset == 64
 
 
+def test_tuning_struct_matches_header():
+    """de_tuning (the one way to tune the library since ABI 5): the ctypes mirror has the header's fields, in the header's order, with the header's types — a
+    field added on one side only would shift every later knob silently (struct_bytes only catches a size change)."""
+    from digital_earth_amd import _native
+    text = open(os.path.join(ROOT, "include", "digital_earth.h")).read()
+    body = re.search(r"typedef struct de_tuning \{(.*?)\} de_tuning;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ctype = {"uint32_t": ctypes.c_uint32, "int32_t": ctypes.c_int32, "uint64_t": ctypes.c_uint64}
+    want = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(uint32_t|int32_t|uint64_t)\s+(.*)", decl.strip(), re.S)
+        if not m:
+            continue
+        for name in m.group(2).split(","):
+            a = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", name)
+            want.append((a.group(1), ctype[m.group(1)] * int(a.group(2)) if a.group(2) else ctype[m.group(1)]))
+    got = list(_native.DeTuning._fields_)
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, a), (_, b) in zip(got, want):
+        assert ctypes.sizeof(a) == ctypes.sizeof(b) and getattr(a, "_length_", 1) == getattr(b, "_length_", 1), n
+    # every environment override of the Python layer names a field of the struct
+    fields = {n for n, _ in got}
+    assert all(f in fields for f, _ in _native.ENV_TUNING.values())
+
+
 def test_no_silent_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
