@@ -192,3 +192,43 @@ def test_fast_math_flag_is_statistically_the_same_image(Renderer):
     assert lit.sum() > 5000 and 0 < (moved & lit).sum() < 0.25 * lit.sum()
     assert abs(f_f.sum() / f_c.sum() - 1.0) < 0.01
     assert rel_l2(f_f, f_c) < rel_l2(frames["other seed"][1], f_c)
+
+
+@pytest.mark.timeout(900)
+def test_tail_chain_with_calls_in_flight_and_partitions(Renderer):
+    """render_kernel_v6's tail chain (a launch exports its workgroups' last paths to a pool, a small launch of the same kernel finishes them) set through
+    de_set_tuning on a live context: many calls of different sizes in flight on all launch slots (every slot's pool and control block in use at once, tail
+    launches of one call queued behind the persistent workgroups of the next), a tile partition and a sample partition — the frame equals the one-launch-per-
+    call frame bit for bit, with one and with two tail levels."""
+    kw = dict(seed=11, texture_source="synthetic", texture_size=(2048, 1024))
+    W, H = 512, 256
+
+    def frame(levels, export0, grid0):
+        r = Renderer((W, H), (0, 1, 0), **kw)
+        r.set_fov(0.42)
+        r.copy_textures()
+        t = r.tuning()
+        t.v6_tail_levels = levels; t.v6_tail_export[0] = export0; t.v6_tail_grid[0] = grid0
+        t.v6_tail_export[1] = 24; t.v6_tail_grid[1] = 4; t.v6_tail_min_paths = 0
+        r.set_tuning(t)
+        r.set_kernel_variant(6)
+        out = []
+        for spp in (3, 1, 5, 2, 7, 1, 1, 4, 6, 2, 3, 5):      # twelve calls, nothing waits in between
+            r.accumulate(spp)
+        assert r.last_call_info()["variant"] == 6
+        out.append(r.fetch_hdr())
+        r.reset_framebuffer(); r.set_tile_partition(2, 5); r.accumulate(6); r.accumulate(3)
+        out.append(r.fetch_hdr())
+        r.set_tile_partition(0, 1); r.reset_framebuffer(); r.set_sample_partition(1, 3); r.accumulate(9)
+        out.append(r.fetch_hdr())
+        launch_ms, drain_ms = r.last_launch_phases()
+        assert 0.0 < drain_ms <= launch_ms < 1e4
+        r.close()
+        return out
+
+    ref = frame(0, 96, 64)
+    assert ref[0].max() > 0 and ref[1].max() > 0 and ref[2].max() > 0
+    for levels, export0, grid0 in ((1, 128, 64), (2, 400, 128), (1, 1024, 8)):
+        got = frame(levels, export0, grid0)
+        for a, b in zip(ref, got):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (levels, export0, grid0)
