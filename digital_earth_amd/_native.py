@@ -112,7 +112,7 @@ class DeTuning(ctypes.Structure):
                 ("v6_min_paths", ctypes.c_uint64), ("v6_service_area", ctypes.c_int32 * 3), ("v6_service_lanes", ctypes.c_int32 * 3),
                 ("v6_yield_max", ctypes.c_int32), ("v6_elsewhere_min", ctypes.c_int32), ("v6_retry", ctypes.c_int32), ("v6_enter_min", ctypes.c_int32),
                 ("v6_flat_min", ctypes.c_int32), ("v6_flat_again", ctypes.c_int32), ("v6_bands", ctypes.c_int32),
-                ("v6_tail_levels", ctypes.c_int32), ("v6_tail_export", ctypes.c_int32 * 2), ("v6_tail_min_paths", ctypes.c_uint32), ("v6_tail_grid", ctypes.c_int32 * 2), ("v6_stats", ctypes.c_int32),
+                ("v6_tail_levels", ctypes.c_int32), ("v6_tail_export", ctypes.c_int32 * 2), ("v6_tail_min_paths", ctypes.c_uint32), ("v6_tail_when_alone", ctypes.c_int32), ("v6_tail_grid", ctypes.c_int32 * 2), ("v6_stats", ctypes.c_int32),
                 ("v2_pend", ctypes.c_int32), ("v2_heavy", ctypes.c_int32), ("v2_b", ctypes.c_int32), ("v2_gas", ctypes.c_int32), ("v2_chunk", ctypes.c_int32),
                 ("v2_waves_per_cu", ctypes.c_int32), ("v2_max_spp", ctypes.c_int32), ("trace", ctypes.c_int32)]
 
@@ -127,7 +127,7 @@ ENV_TUNING = {
     "DE_V6_YIELD": ("v6_yield_max", None), "DE_V6_ELSEWHERE": ("v6_elsewhere_min", None), "DE_V6_RETRY": ("v6_retry", None),
     "DE_V6_ENTER_MIN": ("v6_enter_min", None), "DE_V6_FLAT_MIN": ("v6_flat_min", None), "DE_V6_FLAT_AGAIN": ("v6_flat_again", None), "DE_V6_BANDS": ("v6_bands", None),
     "DE_V6_TAIL": ("v6_tail_levels", None), "DE_V6_TAIL_EXPORT0": ("v6_tail_export", 0), "DE_V6_TAIL_EXPORT1": ("v6_tail_export", 1),
-    "DE_V6_TAIL_MIN_PATHS": ("v6_tail_min_paths", None), "DE_V6_TAIL_GRID0": ("v6_tail_grid", 0), "DE_V6_TAIL_GRID1": ("v6_tail_grid", 1),
+    "DE_V6_TAIL_MIN_PATHS": ("v6_tail_min_paths", None), "DE_V6_TAIL_ALONE": ("v6_tail_when_alone", None), "DE_V6_TAIL_GRID0": ("v6_tail_grid", 0), "DE_V6_TAIL_GRID1": ("v6_tail_grid", 1),
     "DE_V2_THR": ("v2_pend", None), "DE_V2_A": ("v2_heavy", None), "DE_V2_B": ("v2_b", None), "DE_V2_G": ("v2_gas", None),
     "DE_V2_CHUNK": ("v2_chunk", None), "DE_V2_WPC": ("v2_waves_per_cu", None), "DE_V2_MAX_SPP": ("v2_max_spp", None),
 }

@@ -88,6 +88,7 @@ int de_destroy(de_ctx* c) {
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled, c->d_gather};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_issued) hipHostFree(c->h_issued);
 #ifdef DE_LEGACY_VARIANTS
     legacy_destroy(c);
 #endif
@@ -515,7 +516,7 @@ int de_get_tuning(de_ctx* c, de_tuning* t) {
     for (int k = 0; k < 3; ++k) { t->v6_service_area[k] = c->v6_svc_area[k]; t->v6_service_lanes[k] = c->v6_svc[k]; }
     t->v6_yield_max = c->v6_yield; t->v6_elsewhere_min = c->v6_elsewhere; t->v6_retry = c->v6_retry; t->v6_enter_min = c->v6_enter_min;
     t->v6_flat_min = c->v6_flat_min; t->v6_flat_again = c->v6_flat_again; t->v6_bands = c->v6_bands; t->v6_stats = c->v6_stats;
-    t->v6_tail_levels = c->v6_tail_levels; t->v6_tail_min_paths = c->v6_tail_min_paths;
+    t->v6_tail_levels = c->v6_tail_levels; t->v6_tail_min_paths = c->v6_tail_min_paths; t->v6_tail_when_alone = c->v6_tail_when_alone;
     for (int k = 0; k < 2; ++k) { t->v6_tail_export[k] = c->v6_tail_export[k]; t->v6_tail_grid[k] = c->v6_tail_grid[k]; }
     t->v2_pend = c->tune_pend; t->v2_heavy = c->tune_heavy; t->v2_b = c->tune_b; t->v2_gas = c->tune_gas; t->v2_chunk = c->tune_chunk;
     t->v2_waves_per_cu = c->tune_wpc; t->v2_max_spp = c->tune_max_spp;
@@ -537,7 +538,7 @@ int de_set_tuning(de_ctx* c, const de_tuning* t) {
     for (int k = 0; k < 3; ++k) { c->v6_svc_area[k] = t->v6_service_area[k]; c->v6_svc[k] = t->v6_service_lanes[k]; }
     c->v6_yield = t->v6_yield_max; c->v6_elsewhere = t->v6_elsewhere_min; c->v6_retry = t->v6_retry; c->v6_enter_min = t->v6_enter_min;
     c->v6_flat_min = t->v6_flat_min; c->v6_flat_again = t->v6_flat_again; c->v6_bands = t->v6_bands == 8 ? 8 : 1; c->v6_stats = t->v6_stats;
-    c->v6_tail_levels = t->v6_tail_levels; c->v6_tail_min_paths = t->v6_tail_min_paths;
+    c->v6_tail_levels = t->v6_tail_levels; c->v6_tail_min_paths = t->v6_tail_min_paths; c->v6_tail_when_alone = t->v6_tail_when_alone != 0;
     for (int k = 0; k < 2; ++k) { c->v6_tail_export[k] = t->v6_tail_export[k]; c->v6_tail_grid[k] = t->v6_tail_grid[k]; }
     c->tune_pend = t->v2_pend; c->tune_heavy = t->v2_heavy; c->tune_b = t->v2_b; c->tune_gas = t->v2_gas; c->tune_chunk = t->v2_chunk;
     c->tune_wpc = t->v2_waves_per_cu; c->tune_max_spp = t->v2_max_spp;

@@ -128,6 +128,9 @@ struct de_ctx {
     } v6s[DE_MAX_SLOTS];
     int v6_tail_levels = 1, v6_tail_export[2] = {128, 96}, v6_tail_grid[2] = {64, 8};
     uint32_t v6_tail_min_paths = 4u << 20;
+    int v6_tail_when_alone = 0;      // 1: export even when no launch is queued behind (tests; default: only then, see render_kernel_v6.hip schedule())
+    uint32_t* h_issued = nullptr;    // pinned, device-visible: the number of the newest render_kernel_v6 launch with a successor on another launch slot (read once per workgroup)
+    uint32_t v6_launch_seq = 0;
     int v6_bands = 8;                // work counters of a launch: 8 = one band of the image per XCD, 1 = one for the whole launch (render_kernel_v6.hip: run_primary)
     int v6_stats = 0;                // 1: the instrumented kernel (env DE_V6_STATS; de_debug_v6_stats)
     int v6_svc[3] = {24, 24, 20};    // idle lanes at which a loop stage services (env DE_V6_SVC_ST / _GAS / _CLOUD)

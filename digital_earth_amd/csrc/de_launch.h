@@ -227,7 +227,20 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     dim3 grid(by_work < S.n_wg ? (by_work ? by_work : 1u) : S.n_wg), block(64 * DE_V6_WAVES);
     // The frame's chain (render_kernel_v6.hip: "The tail"): a launch that fills the GPU exports its workgroups' last paths instead of waiting for
     // them, and up to two small launches of the same kernel — on this stream: the pool is complete when they start — finish them.
-    const int levels = A.n_items >= c->v6_tail_min_paths ? c->v6_tail_levels : 0;      // (4 Mi paths by default: launches that fill the GPU several times over)
+    const int levels = A.n_items >= c->v6_tail_min_paths ? c->v6_tail_levels : 0;
+    if (!c->h_issued) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&c->h_issued), 64, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        c->h_issued[0] = 0u;
+    }
+    uint32_t* d_issued = nullptr;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d_issued), c->h_issued, 0);
+    if (e != hipSuccess) return e;
+    // This launch's number.  The word the kernels read holds the number of the newest launch that HAS A SUCCESSOR ON ANOTHER STREAM: written here, when that
+    // successor is issued (a successor on the same launch slot waits for the whole chain anyway: exporting would only add the tail launch's latency)
+    const uint32_t seq = ++c->v6_launch_seq;
+    if (c->last_slot >= 0 && c->last_slot != idx) __atomic_store_n(c->h_issued, seq - 1u, __ATOMIC_RELEASE);
+    A.issued = d_issued; A.seq = c->v6_tail_when_alone ? 0xffffffffu : seq;      // (4 Mi paths by default: launches that fill the GPU several times over)
     const bool fast = (c->p.flags & DE_FLAG_FAST_MATH) != 0u;
     for (int l = 0; l <= levels; ++l) {
         A.level = (uint32_t)l;

@@ -118,6 +118,8 @@ struct Args {
     uint32_t export_at;         // > 0: a workgroup with nothing left to start and at most this many paths alive exports them to pool_out and exits
     uint4* pool_in; uint4* pool_out;
     uint32_t cap_in, cap_out;   // entries the pools hold
+    const uint32_t* issued;     // host-visible: the number of the context's newest launch that has a successor on another stream — a workgroup only exports when this launch (seq) has one, see schedule()
+    uint32_t seq;               // this launch's number in that count; 0xffffffff: export whether or not anything follows (tests, de_tuning.v6_tail_when_alone)
 };
 template <int... T> struct Targets {};
 
@@ -149,17 +151,18 @@ struct Cfg {
     uint32_t flat_min, flat_again;
     uint32_t bands, xcd;        // xcd: the XCD this workgroup runs on (HW_REG_XCC_ID)
     uint4* pool_in; uint4* pool_out;
-    uint32_t level, export_at, cap_in, cap_out;
+    const uint32_t* issued;
+    uint32_t level, export_at, cap_in, cap_out, seq, pad_;
 };
-static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 144, "Cfg is copied dword by dword");
+static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 160, "Cfg is copied dword by dword");
 
 __shared__ uint4 s_rec[3u * DE_V6_P];                // the record slots: three 16-byte parts, part-major ...
 __shared__ uint2 s_rec2[DE_V6_P];                    // ... and one of 8 bytes
 __shared__ uint16_t s_rings[(NQ + 1) * DE_V6_CAP];   // NR rings of slot numbers
-__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16, drain statistics at 17, "exporting" at 18
+__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16, drain statistics at 17, "exporting" at 18, waves that may still start paths at 19, the export decision at 20
 __shared__ float s_node_val[64];
 __shared__ unsigned long long s_stats[64];
-__shared__ uint32_t s_cfg[36];
+__shared__ uint32_t s_cfg[40];
 
 DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -408,8 +411,21 @@ struct Wave {
                 bool exporting = __builtin_amdgcn_readlane((int)two, 0) != 0;
                 const bool starters = __builtin_amdgcn_readlane((int)two, 1) != 0;
                 if (!exporting && !starters && live != 0u && live <= A.export_at) {
-                    if (lane_id() == 0) __hip_atomic_store(cw + 18, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    exporting = true;
+                    // Export only if another launch of this context is queued behind this one: the slots this workgroup frees are then taken at once, which is
+                    // what the chain is for; a launch with nothing behind it (a frame rendered alone, the last call before a fetch) would only end later for it —
+                    // the tail launch cannot start before the last workgroup here has exported.  Decided once per workgroup (one read of host memory).
+                    uint32_t dec = uni(ld_wg(cw + 20));      // 0: not decided, 1: export, 2: finish in place
+                    if (dec == 0u) {
+                        if (lane_id() == 0) {
+                            dec = (A.seq == 0xffffffffu || (int)(__hip_atomic_load(A.issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) >= 0) ? 1u : 2u;
+                            __hip_atomic_store(cw + 20, dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        dec = uni(dec);
+                    }
+                    if (dec == 1u) {
+                        if (lane_id() == 0) __hip_atomic_store(cw + 18, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        exporting = true;
+                    }
                 }
                 if (exporting) {
                     if (best > 0) return Q_EXPORT;
@@ -810,7 +826,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         c.svc_area[0] = A.svc_area[0]; c.svc_area[1] = A.svc_area[1]; c.svc_area[2] = A.svc_area[2];
         c.yield_max = A.yield_max; c.elsewhere_min = A.elsewhere_min; c.retry = A.retry; c.enter_min = A.enter_min; c.flat_min = A.flat_min; c.flat_again = A.flat_again;
         c.bands = A.bands == 8u ? 8u : 1u;
-        c.pool_in = A.pool_in; c.pool_out = A.pool_out; c.level = A.level; c.export_at = A.export_at; c.cap_in = A.cap_in; c.cap_out = A.cap_out;
+        c.pool_in = A.pool_in; c.pool_out = A.pool_out; c.level = A.level; c.export_at = A.export_at; c.cap_in = A.cap_in; c.cap_out = A.cap_out; c.issued = A.issued; c.seq = A.seq; c.pad_ = 0u;
         { uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); c.xcd = xcc & 7u; }
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) s_cfg[k] = src[k];

@@ -259,6 +259,9 @@ typedef struct de_tuning {
     int32_t v6_tail_export[2];        /* level k exports when at most this many paths are alive in the workgroup (1 .. 1024) */
     uint32_t v6_tail_min_paths;       /* ... and start at least this many paths (default 4 Mi: below that the tail launch's latency — the chain of a frame rendered alone ends ~1 ms
                                          later — outweighs the workgroup slots it frees; the interactive one-sample frame stays one launch) */
+    int32_t v6_tail_when_alone;       /* 0 (default): a launch's workgroups export only when another launch of the context is already queued behind it — then the slots they free are
+                                         taken at once; a call with nothing behind it (a frame rendered alone) finishes in place: it would end ~1 ms LATER with a tail launch.
+                                         1: export regardless (tests) */
     int32_t v6_tail_grid[2];          /* workgroups of tail launch k + 1 (they must hold what level k can export: grid x 1120 >= workgroups of level k x v6_tail_export[k]) */
     int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
     int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */

@@ -58,7 +58,7 @@ def test_block_scheduler_settings_do_not_move_bits(Renderer, monkeypatch, yield_
     further launches from pools in HBM (render_kernel_v6.hip, "The tail"), forced on for these small frames; with yields off (first row) the
     records in the loop stages' lanes only come back through the export's own yield."""
     monkeypatch.setenv("DE_V6_TAIL", str(tail[0])); monkeypatch.setenv("DE_V6_TAIL_EXPORT0", str(tail[1])); monkeypatch.setenv("DE_V6_TAIL_GRID0", str(tail[2]))
-    monkeypatch.setenv("DE_V6_TAIL_EXPORT1", "40"); monkeypatch.setenv("DE_V6_TAIL_GRID1", "8"); monkeypatch.setenv("DE_V6_TAIL_MIN_PATHS", "0")
+    monkeypatch.setenv("DE_V6_TAIL_EXPORT1", "40"); monkeypatch.setenv("DE_V6_TAIL_GRID1", "8"); monkeypatch.setenv("DE_V6_TAIL_MIN_PATHS", "0"); monkeypatch.setenv("DE_V6_TAIL_ALONE", "1")      # export also when no launch is queued behind (the default exports only then)
     monkeypatch.setenv("DE_V6_YIELD", str(yield_max)); monkeypatch.setenv("DE_V6_RETRY", str(retry))
     monkeypatch.setenv("DE_V6_ELSEWHERE", str(elsewhere)); monkeypatch.setenv("DE_V6_ENTER_MIN", str(enter_min))
     monkeypatch.setenv("DE_V6_FLAT_AGAIN", str(flat_again)); monkeypatch.setenv("DE_V6_BANDS", str(bands))

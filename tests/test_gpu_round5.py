@@ -135,7 +135,7 @@ def test_ring_protocol_on_small_pools(tmp_path):
     for name, _flags in VARIANTS:
         lib = os.path.join(ROOT, "build", "ab", name + ".so")
         assert os.path.exists(lib), "variant library %s missing: run __graft_entry__.build()" % lib
-        env2 = dict(env, DE_LIB_PATH=lib, DE_TEST_REPS="3", DE_V6_TAIL_MIN_PATHS="0")      # the tail chain too (its export threshold, 96 paths, is above these pools' size)
+        env2 = dict(env, DE_LIB_PATH=lib, DE_TEST_REPS="3", DE_V6_TAIL_MIN_PATHS="0", DE_V6_TAIL_ALONE="1")      # the tail chain too (its export threshold, 96 paths, is above these pools' size)
         path = str(tmp_path / (name + ".npz"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env2, timeout=1800)
         got = np.load(path)
@@ -203,13 +203,14 @@ def test_tail_chain_with_calls_in_flight_and_partitions(Renderer):
     kw = dict(seed=11, texture_source="synthetic", texture_size=(2048, 1024))
     W, H = 512, 256
 
-    def frame(levels, export0, grid0):
+    def frame(levels, export0, grid0, alone=1):
         r = Renderer((W, H), (0, 1, 0), **kw)
         r.set_fov(0.42)
         r.copy_textures()
         t = r.tuning()
         t.v6_tail_levels = levels; t.v6_tail_export[0] = export0; t.v6_tail_grid[0] = grid0
         t.v6_tail_export[1] = 24; t.v6_tail_grid[1] = 4; t.v6_tail_min_paths = 0
+        t.v6_tail_when_alone = alone      # 0 = as shipped: a launch exports only when another call is queued behind it on another launch slot (most of the twelve below are)
         r.set_tuning(t)
         r.set_kernel_variant(6)
         out = []
@@ -228,7 +229,7 @@ def test_tail_chain_with_calls_in_flight_and_partitions(Renderer):
 
     ref = frame(0, 96, 64)
     assert ref[0].max() > 0 and ref[1].max() > 0 and ref[2].max() > 0
-    for levels, export0, grid0 in ((1, 128, 64), (2, 400, 128), (1, 1024, 8)):
-        got = frame(levels, export0, grid0)
+    for levels, export0, grid0, alone in ((1, 128, 64, 0), (1, 128, 64, 1), (2, 400, 128, 1), (1, 1024, 8, 0)):
+        got = frame(levels, export0, grid0, alone)
         for a, b in zip(ref, got):
-            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (levels, export0, grid0)
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (levels, export0, grid0, alone)
