@@ -60,6 +60,8 @@ def parse():
                          "render_kernel_v6, always runs two workgroups of 12 waves per CU and ignores this")
     ap.add_argument("--sync-frames", action="store_true",
                     help="wait for every frame before submitting the next (profiling: frames do not overlap in the trace)")
+    ap.add_argument("--collective", choices=("reduce", "gather"), default="reduce",
+                    help="N > 1, tile partition, --reduce torch: sum-reduce of the whole HDR buffer (default) or a gather of each rank's own pixels (1/N of the bytes; SURVEY §8e)")
     ap.add_argument("--serial-frames", action="store_true",
                     help="one launch at a time (launch slots = 1): the collective of frame k never waits behind frame k+1's persistent waves")
     ap.add_argument("--dump-hdr", default=None, help="rank 0: save the assembled HDR frame of the LAST step as .npy (tests)")
@@ -197,7 +199,7 @@ def main():
                 return box[0]
             frames.append(parallel.LibraryComm(rk, rank, world, exchange, split=args.split))
         else:
-            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index, priority=-1), split=args.split))
+            frames.append(parallel.DistributedFrame(rk, rank, world, device_index, stream=torch.cuda.Stream(device=device_index, priority=-1), split=args.split, collective=args.collective))
         if args.simulate_world > 1 and world == 1:
             if args.split == "samples":
                 rk.set_sample_partition(0, args.simulate_world)
@@ -411,7 +413,7 @@ def main():
         "config": {"workload": "%dx%d, %d spp, full spectral Rayleigh+Mie+O3+clouds, quality-%d synthetic maps%s, %s, "
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
                                                          args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
-                   "parallelism": (("tile-partition x%d + %s reduce (%s)" if args.split == "tiles" else "sample-partition x%d + %s rank-ordered gather-sum (%s)") % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1
+                   "parallelism": ((("tile-partition x%d + %s reduce (%s)" if args.collective == "reduce" else "tile-partition x%d + %s gather of the owned pixels (%s)") if args.split == "tiles" else "sample-partition x%d + %s rank-ordered gather-sum (%s)") % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1
                                   else ("single GPU" if args.simulate_world <= 1 else "single GPU rendering rank 0's share of a %s partition x%d (no collective)" % (args.split, args.simulate_world)),
                    "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3,
                    "waves_per_cu": 24 if timed_info["variant"] == 6 else wpc,      # render_kernel_v6: two workgroups of 12 waves per CU (80 VGPRs); the wave budget knob belongs to the state machine

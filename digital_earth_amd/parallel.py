@@ -7,8 +7,10 @@ zero-initialised HDR buffer; one sum-reduce of that buffer to rank 0 per fetch a
 disjoint, so every pixel is x + 0 + ... + 0: exact).  The RNG stream of a sample depends only on
 (seed, absolute pixel, sample index), so the assembled frame is bit-identical to a 1-GPU render.
 
-Two ways to run the collective:
+Ways to run the collective:
   * `reduce_hdr` — torch.distributed on a torch-owned HDR tensor (default; what bench.py times);
+  * `gather_hdr_tiles` — the same frame from a gather of the owned pixels only (1/world of the bytes; `DistributedFrame(collective="gather")`,
+    `bench.py --collective gather`);
   * `LibraryComm` — the library's own RCCL communicator behind the C ABI (`de_comm_init` / `de_reduce`,
     include/digital_earth.h), for hosts without PyTorch; only the 128-byte unique id has to travel between ranks.
 
@@ -71,6 +73,53 @@ def reduce_hdr(hdr, dst=0, group=None, out=None):
     return hdr
 
 
+_TILE_INDEX_CACHE = {}
+
+
+def _owned_pixel_index(width, height, rank, world, device):
+    """Linear pixel indices (x * H + y, the HDR buffer's order) of the pixels `rank` owns, as an int64 tensor on `device` (cached)."""
+    import torch
+    key = (width, height, rank, world, str(device))
+    if key not in _TILE_INDEX_CACHE:
+        _TILE_INDEX_CACHE[key] = torch.from_numpy(np.flatnonzero(owned_pixel_mask(width, height, rank, world).ravel())).to(device)
+    return _TILE_INDEX_CACHE[key]
+
+
+def gather_hdr_tiles(hdr, width, height, dst=0, group=None, out=None):
+    """The other collective of a TILE partition ("a direct 7-peer gather of 1/8-size tiles ... is the bandwidth-optimal variant"):
+    every rank packs the pixels it owns (12 W H / world bytes: 3.1 MB at 1080p and 8 ranks instead of the 24.9 MB a sum-reduce of the whole buffer
+    moves per rank), one gather onto `dst`, which scatters each rank's pixels into place.  The assembled frame holds every rank's bits UNCHANGED
+    (a copy instead of x + 0 + ... + 0) — identical to `reduce_hdr`'s except that a -0.0 stays -0.0.  out=None: the root's own buffer becomes the
+    frame; out=tensor: out of place (progressive display).  gloo + device tensors: staged through host memory, as in reduce_hdr."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        if out is not None:
+            out.copy_(hdr)
+            return out
+        return hdr
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    staged = hdr.is_cuda and dist.get_backend(group) != "nccl"
+    counts = [int(n) * TILE * TILE for n in tiles_per_rank(width, height, world)]
+    n_max = max(counts)
+    mine = _owned_pixel_index(width, height, rank, world, hdr.device)
+    send = torch.zeros(n_max, 3, dtype=hdr.dtype, device=hdr.device)
+    send[:counts[rank]] = hdr.view(-1, 3)[mine]
+    if staged:
+        send = send.cpu()
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gather_list=parts, dst=dst, group=group)
+    if rank == dst:
+        target = out if out is not None else hdr
+        tv = target.view(-1, 3)
+        for r in range(world):
+            if r == rank and out is None:
+                continue                                     # in place: the root's own pixels are where they belong
+            idx = _owned_pixel_index(width, height, r, world, hdr.device)
+            tv[idx] = parts[r][:counts[r]].to(hdr.device)
+    return out if out is not None else hdr
+
+
 def reduce_hdr_ordered(hdr, dst=0, group=None, out=None):
     """The collective of a SAMPLE partition: the per-rank buffers (partial sums of every pixel) are gathered on `dst` and added in RANK
     order — ((h0 + h1) + h2) + ... — so the result does not depend on how RCCL would have ordered a sum-reduce.  out=None: the root's
@@ -103,10 +152,13 @@ class DistributedFrame:
     Lifetime: the Renderer is handed references to the tensor and the stream (`Renderer._bound`), so neither can be
     collected while the context still points at them; `close()` gives the context back its own buffer and stream."""
 
-    def __init__(self, renderer, rank, world, device_index, stream=None, split="tiles"):
+    def __init__(self, renderer, rank, world, device_index, stream=None, split="tiles", collective="reduce"):
         import torch
         if split not in ("tiles", "samples"):
             raise ValueError(split)
+        if collective not in ("reduce", "gather"):
+            raise ValueError(collective)
+        self.collective = collective                 # tile partition only: sum-reduce of the whole buffer (default) or gather of the owned pixels
         self.torch = torch
         self.r = renderer
         self.rank, self.world, self.split = rank, world, split
@@ -136,7 +188,12 @@ class DistributedFrame:
         # after the launches — they run on the context's launch slots, not on this stream
         self.r.flush()
         self._ev[0].record(self.stream)
-        (reduce_hdr_ordered if self.split == "samples" else reduce_hdr)(self.hdr, dst=0, out=out)
+        if self.split == "samples":
+            reduce_hdr_ordered(self.hdr, dst=0, out=out)
+        elif self.collective == "gather":
+            gather_hdr_tiles(self.hdr, self.r.image_res[0], self.r.image_res[1], dst=0, out=out)
+        else:
+            reduce_hdr(self.hdr, dst=0, out=out)
         self._ev[1].record(self.stream)
         self._timed = True
 

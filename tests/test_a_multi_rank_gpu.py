@@ -81,7 +81,7 @@ def test_progressive_frames_on_two_ranks(tmp_path):
     assert p1.returncode == 0, p1.stderr[-3000:]
     port = 29700 + (os.getpid() % 1500)
     p2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), "bench.py", "--gpus", "2", "--progressive", "2", "--dump-hdr", multi] + common,
+               "--master-port", str(port), "bench.py", "--gpus", "2", "--progressive", "2", "--collective", "gather", "--dump-hdr", multi] + common,      # the gather of the owned pixels, out of place (the in-place sum-reduce: the test above)
               env_extra={"DE_DIST_BACKEND": "gloo"})
     assert p2.returncode == 0, (p2.stdout[-2000:], p2.stderr[-4000:])
     j2 = _json_line(p2.stdout)
@@ -150,7 +150,7 @@ def _visible_gpus():
 @pytest.mark.gpu
 @pytest.mark.timeout(1800)
 @pytest.mark.skipif(_visible_gpus() < 2, reason="needs two MI355X: the builder's box has one (this is the first test to run on a multi-GPU node)")
-@pytest.mark.parametrize("reduce_impl", ["torch", "lib"])
+@pytest.mark.parametrize("reduce_impl", ["torch", "lib", "torch-gather"])
 def test_two_gpus_rccl_reduce_matches_one_rank(tmp_path, reduce_impl):
     """RCCL between two devices: torch.distributed's reduce on the bound tensor, and the library's own communicator
     (de_comm_init / de_reduce: hand-declared ncclCommInitRank ABI, ncclFloat32 / ncclSum enums).  The assembled frame equals the
@@ -160,7 +160,7 @@ def test_two_gpus_rccl_reduce_matches_one_rank(tmp_path, reduce_impl):
     assert p1.returncode == 0, p1.stderr[-3000:]
     port = 29900 + (os.getpid() % 1500)
     p2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), "bench.py", "--gpus", "2", "--reduce", reduce_impl, "--dump-hdr", multi] + COMMON)
+               "--master-port", str(port), "bench.py", "--gpus", "2", "--dump-hdr", multi] + (["--collective", "gather"] if reduce_impl == "torch-gather" else ["--reduce", reduce_impl]) + COMMON)
     assert p2.returncode == 0, (p2.stdout[-2000:], p2.stderr[-4000:])
     j2 = _json_line(p2.stdout)
     assert j2["devices_seen"] == 2 and j2["multi_gpu_parity"]["bit_identical_fraction"] == 1.0
