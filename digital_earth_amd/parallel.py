@@ -76,21 +76,24 @@ def reduce_hdr(hdr, dst=0, group=None, out=None):
 _TILE_INDEX_CACHE = {}
 
 
-def _owned_pixel_index(width, height, rank, world, device):
-    """Linear pixel indices (x * H + y, the HDR buffer's order) of the pixels `rank` owns, as an int64 tensor on `device` (cached)."""
+def _owned_pixel_index(width, height, rank, world, device, layout):
+    """Linear pixel indices of the pixels `rank` owns, as an int64 tensor on `device` (cached).  layout "WH": x * H + y — the (W, H, 3) arrays the API hands
+    out (fetch_hdr, the reference's field); "HW": y * W + x — the library's accumulation buffer on the device (a bound HDR tensor)."""
     import torch
-    key = (width, height, rank, world, str(device))
+    key = (width, height, rank, world, str(device), layout)
     if key not in _TILE_INDEX_CACHE:
-        _TILE_INDEX_CACHE[key] = torch.from_numpy(np.flatnonzero(owned_pixel_mask(width, height, rank, world).ravel())).to(device)
+        mask = owned_pixel_mask(width, height, rank, world)
+        _TILE_INDEX_CACHE[key] = torch.from_numpy(np.flatnonzero((mask if layout == "WH" else mask.T).ravel())).to(device)
     return _TILE_INDEX_CACHE[key]
 
 
-def gather_hdr_tiles(hdr, width, height, dst=0, group=None, out=None):
+def gather_hdr_tiles(hdr, width, height, dst=0, group=None, out=None, layout="WH"):
     """The other collective of a TILE partition ("a direct 7-peer gather of 1/8-size tiles ... is the bandwidth-optimal variant"):
     every rank packs the pixels it owns (12 W H / world bytes: 3.1 MB at 1080p and 8 ranks instead of the 24.9 MB a sum-reduce of the whole buffer
     moves per rank), one gather onto `dst`, which scatters each rank's pixels into place.  The assembled frame holds every rank's bits UNCHANGED
     (a copy instead of x + 0 + ... + 0) — identical to `reduce_hdr`'s except that a -0.0 stays -0.0.  out=None: the root's own buffer becomes the
-    frame; out=tensor: out of place (progressive display).  gloo + device tensors: staged through host memory, as in reduce_hdr."""
+    frame; out=tensor: out of place (progressive display).  gloo + device tensors: staged through host memory, as in reduce_hdr.  `layout`: the pixel order
+    of `hdr` (see _owned_pixel_index)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
@@ -102,7 +105,7 @@ def gather_hdr_tiles(hdr, width, height, dst=0, group=None, out=None):
     staged = hdr.is_cuda and dist.get_backend(group) != "nccl"
     counts = [int(n) * TILE * TILE for n in tiles_per_rank(width, height, world)]
     n_max = max(counts)
-    mine = _owned_pixel_index(width, height, rank, world, hdr.device)
+    mine = _owned_pixel_index(width, height, rank, world, hdr.device, layout)
     send = torch.zeros(n_max, 3, dtype=hdr.dtype, device=hdr.device)
     send[:counts[rank]] = hdr.view(-1, 3)[mine]
     if staged:
@@ -115,7 +118,7 @@ def gather_hdr_tiles(hdr, width, height, dst=0, group=None, out=None):
         for r in range(world):
             if r == rank and out is None:
                 continue                                     # in place: the root's own pixels are where they belong
-            idx = _owned_pixel_index(width, height, r, world, hdr.device)
+            idx = _owned_pixel_index(width, height, r, world, hdr.device, layout)
             tv[idx] = parts[r][:counts[r]].to(hdr.device)
     return out if out is not None else hdr
 
@@ -191,7 +194,7 @@ class DistributedFrame:
         if self.split == "samples":
             reduce_hdr_ordered(self.hdr, dst=0, out=out)
         elif self.collective == "gather":
-            gather_hdr_tiles(self.hdr, self.r.image_res[0], self.r.image_res[1], dst=0, out=out)
+            gather_hdr_tiles(self.hdr, self.r.image_res[0], self.r.image_res[1], dst=0, out=out, layout="HW")      # the bound tensor IS the device buffer: [H][W][3]
         else:
             reduce_hdr(self.hdr, dst=0, out=out)
         self._ev[1].record(self.stream)

@@ -182,8 +182,10 @@ def _gather_worker(rank, world, port, out_path):
     parallel.gather_hdr_tiles(hdr, W, H, dst=0, out=work)
     assert torch.equal(hdr, before)
     parallel.gather_hdr_tiles(hdr, W, H, dst=0)            # in place: the root's buffer becomes the frame
+    dev = torch.from_numpy(np.ascontiguousarray(part.transpose(1, 0, 2))).reshape(-1)     # the library's device buffer: [H][W][3], flat (what a bound tensor is)
+    parallel.gather_hdr_tiles(dev, W, H, dst=0, layout="HW")
     if rank == 0:
-        np.save(out_path, np.stack([work.numpy(), hdr.numpy()]))
+        np.save(out_path, np.stack([work.numpy(), hdr.numpy(), dev.reshape(H, W, 3).numpy().transpose(1, 0, 2)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -199,3 +201,4 @@ def test_three_rank_tile_gather_equals_the_single_process_frame(tmp_path):
     full = _frame(0, 1)
     assert (got[0].view(np.uint32) == full.view(np.uint32)).all()
     assert (got[1].view(np.uint32) == full.view(np.uint32)).all()
+    assert (got[2].view(np.uint32) == full.view(np.uint32)).all()      # the device buffer's pixel order
