@@ -26,7 +26,9 @@
 // with few busy lanes suspends its records (the loop's state travels in the record and in spare words of the cold record, bit for bit) and
 // hands them back to its own ring, where they fill the idle lanes of another wave; (2) every stage is a separate, non-inlined device
 // function: 76-80 VGPRs each instead of 128 + spills for the seven inlined, so six waves per SIMD fit; (3) 56-byte records: the LDS holds
-// 1.46 record slots per lane at that occupancy, and slots per lane is what bounds the design.
+// 1.46 record slots per lane at that occupancy, and slots per lane is what bounds the design; (4) THE TAIL (round 5, see "The tail" below):
+// a launch with another one queued behind it does not keep half a CU's LDS for its last handful of paths — a workgroup exports them to a
+// pool in HBM and exits, and a 64-workgroup launch of this same kernel (TAIL = true) finishes them.
 #include "de_stages.h"
 
 namespace bs {
