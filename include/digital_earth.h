@@ -233,7 +233,7 @@ int de_enable_counters(de_ctx* ctx, int enable);
  *                calls (and counting launches) run the state machine (variant 2), overlapping through the launch slots.  The choice
  *                depends on the call's size only and moves time, never bits.
  *   2            wave-level state machine only (render_kernel_v2.hip)
- *   6            per-CU stage scheduler: ONE launch, two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
+ *   6            per-CU stage scheduler: ONE launch (+ a small tail launch of the same kernel for big calls, de_tuning.v6_tail_*), two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
  * Variants 1 (per-lane loops), 3 (wavefront pipeline through HBM stage queues; with DE_AUTO_V6=0 the launch policy of rounds 3-4) and 5 (stage
  * scheduler over HBM queues) are further statements of path_tracer kept for the cross-check tests: the LEGACY library only
  * (libdigitalearth_hip_legacy.so, include/digital_earth_legacy.h); this library answers DE_ERR_INVALID to them.
