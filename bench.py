@@ -27,12 +27,42 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+# BASELINE.json `configs` by name (configs[0] — 256x256, 4 spp, one wavelength, flat Earth — is the reference's CPU-runnable case: a parity test,
+# tests/test_gpu_parity.py, not a bench workload).  `--config NAME` sets size / spp / camera preset / map variant / progressive interval from this table
+# and the line's `metric` names the config; the presets are the reference's own `config - *.txt` files (digital_earth_amd/data/configs, sha256-pinned).
+# cfg5's camera-response curve is taken BY NAME: the preset's index 12 counts os.listdir order on the author's machine; the name is the one
+# the executed reference resolved it to in the build container (tests/golden/ref_q2.npz: apollo_crf_name).
+CONFIGS = {
+    "cfg2": dict(index=1, width=1920, height=1080, spp=64, preset=None, cloud_heavy=False, progressive=0, crf_name=None),
+    "cfg3": dict(index=2, width=1920, height=1080, spp=256, preset="config - florida.txt", cloud_heavy=False, progressive=0, crf_name=None),
+    "cfg4": dict(index=3, width=3840, height=2160, spp=128, preset="config - sunset hurricane.txt", cloud_heavy=True, progressive=0, crf_name=None),
+    "cfg5": dict(index=4, width=1920, height=1080, spp=1024, preset="config - Apollo 11.txt", cloud_heavy=False, progressive=128, crf_name="kaf2001CD.rf"),
+}
+# sparse-tile oracle check of a config at its FULL sample count: every `world`-th 8x8 tile (owner rule of the tile partition), ~0.5 M paths on the host
+SPARSE_CHECK = {"cfg2": (5, 997), "cfg3": (11, 997), "cfg4": (23, 2003), "cfg5": (41, 4051)}
+
+
+def metric_name(width, height, spp, preset, cloud_heavy, progressive):
+    extra = ""
+    if preset:
+        extra += ", '%s'" % preset
+    if cloud_heavy:
+        extra += ", cloud-heavy maps"
+    if progressive:
+        extra += ", progressive every %d" % progressive
+    return "Msamples/sec (%dx%d, %d spp%s) spectral path tracing" % (width, height, spp, extra)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="a BASELINE.json config by name: sets --width/--height/--spp/--preset/--cloud-heavy/--progressive (and cfg5's film curve) and the line's metric string; "
+                         "default: cfg2 = BASELINE configs[1], the configuration the metric is quoted on")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default 1-GPU cfg2 run: skip the short (2-step) legs of cfg3 / cfg4 / cfg5 that follow the timed region (`other_configs` in the line)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
@@ -66,13 +96,30 @@ def parse():
                     help="one launch at a time (launch slots = 1): the collective of frame k never waits behind frame k+1's persistent waves")
     ap.add_argument("--dump-hdr", default=None, help="rank 0: save the assembled HDR frame of the LAST step as .npy (tests)")
     ap.add_argument("--check-spp", type=int, default=2, help="N > 1: spp of the untimed parity check of the assembled frame against a 1-rank render on rank 0 (0 = skip)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.crf_name = None
+    args.config_name = None
+    if args.config:
+        c = CONFIGS[args.config]
+        args.width, args.height, args.spp, args.preset = c["width"], c["height"], c["spp"], c["preset"]
+        args.cloud_heavy, args.progressive, args.crf_name = c["cloud_heavy"], c["progressive"], c["crf_name"]
+        args.tex_quality = 2
+        args.config_name = args.config
+    else:
+        # flags that happen to spell a BASELINE config are named as one; anything else gets a metric string that says what ran
+        for name, c in CONFIGS.items():
+            if (args.width, args.height, args.spp, args.preset, bool(args.cloud_heavy), args.progressive) == (c["width"], c["height"], c["spp"], c["preset"], c["cloud_heavy"], c["progressive"]) \
+                    and args.tex_quality == 2 and not args.tex_size and c["crf_name"] is None:
+                args.config_name = name
+    return args
 
 
-def apply_preset(r, name):
+def apply_preset(r, name, crf_name=None):
     from digital_earth_amd.earth_viewer import load_config
     cfg = load_config(os.path.join(ROOT, "digital_earth_amd", "data", "configs", name))
     cfg.apply(r)
+    if crf_name:
+        r.set_crf(r.crf_names.index(crf_name))
 
 
 def physical_cores():
@@ -128,6 +175,102 @@ def cpu_baseline(r, args, maps):
                      "reference algorithm (oracle/), OpenMP over 16x8 pixel blocks" % (W, H, args.cpu_spp, n, dt)}
     # the same sample doubles as a full-size parity check of the GPU image (1 spp at matched seed)
     return out, o
+
+
+def sparse_oracle_check(name, rk, maps, seed):
+    """The frame `rk` holds (the config's FULL sample count) against the oracle on every `world`-th 8x8 tile: bit-identical fraction of those pixels."""
+    import ctypes
+    import numpy as np
+    from digital_earth_amd import luts, parallel
+    from oracle import oracle_binding as ob
+    W, H = rk.image_res
+    rank, world = SPARSE_CHECK[name]
+    g = rk.fetch_hdr()
+    o = ob.Oracle(W, H)
+    _, crf = luts.load_crfs()
+    o.upload_luts(luts.load_cie(), luts.load_srgb2spec(), luts.load_o3(), crf)
+    for s in range(7):
+        o.upload_texture(s, maps[s])
+    p = ob.DeParams()
+    ctypes.memmove(ctypes.byref(p), ctypes.byref(rk._params), ctypes.sizeof(p))
+    o.set_params(p)
+    t0 = time.perf_counter()
+    o.accumulate(rk.current_spp, seed, rank, world)
+    dt = time.perf_counter() - t0
+    mask = parallel.owned_pixel_mask(W, H, rank, world)
+    c = o.fetch_hdr()
+    same = float((c[mask].view(np.uint32) == g[mask].view(np.uint32)).mean())
+    del o
+    return {"bit_identical_vs_oracle_on_sparse_tiles": same, "sparse_tiles": "every %dth 8x8 tile (rank %d of the tile-partition rule), %d pixels x %d spp, oracle %.1f s" % (world, rank, int(mask.sum()), rk.current_spp, dt)}
+
+
+def run_other_config(name, r_main, maps, device_index, steps=2):
+    """BASELINE cfg3 / cfg4 / cfg5 for a few steps on this GPU (after the timed cfg2 region, untimed by the contract): ms per step with frames back to back,
+    the launch's own duration on a frame rendered alone, the §8(d) roofline fraction from THIS camera's tap counts, and the frame at the config's full
+    sample count against the oracle on sparse tiles.  The maps are the resident ones (borrowed); cfg4 owns its cloud-heavy cloud map."""
+    import numpy as np
+    from digital_earth_amd.renderer import Renderer
+    from digital_earth_amd import textures as T
+    c = CONFIGS[name]
+    W, H, spp = c["width"], c["height"], c["spp"]
+    rk = Renderer((W, H), (0, 1, 0), device=device_index, texture_source="synthetic", texture_quality=2, cloud_heavy=c["cloud_heavy"], seed=0)
+    try:
+        apply_preset(rk, c["preset"], c["crf_name"])
+        rk.share_textures_from(r_main)
+        my_maps = maps
+        if c["cloud_heavy"]:
+            rk.copy_texture(T.CLOUDS)
+            if maps is not None:
+                my_maps = list(maps)
+                my_maps[T.CLOUDS] = rk.download_texture(T.CLOUDS)
+        rk.set_launch_slots(8, 3)
+        rk.enable_counters(True)
+        rk.reset_framebuffer()
+        rk.accumulate(2)
+        rk.synchronize()
+        cnt = rk.counters()
+        rk.enable_counters(False)
+        n_r8, n_rgb = cnt["taps_r8"] / max(cnt["samples"], 1), cnt["taps_rgb8"] / max(cnt["samples"], 1)
+        b_sample = 8.0 + 4.0 * n_r8 + 16.0 * n_rgb
+        every = c["progressive"] if c["progressive"] > 0 else spp
+
+        def step(lone=False):
+            ms = 0.0
+            rk.reset_framebuffer()
+            done = 0
+            while done < spp:
+                n = min(every, spp - done)
+                rk.accumulate(n)
+                if lone:
+                    rk.synchronize()
+                    ms += rk.last_accumulate_ms()
+                if c["progressive"] > 0:
+                    rk.render_to_image_device()          # the progressive display after every K samples
+                done += n
+            if c["progressive"] <= 0:
+                rk.render_to_image_device()
+            return ms
+        step()                                            # allocations of every launch slot: untimed
+        rk.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        rk.synchronize()
+        ms_per_step = (time.perf_counter() - t0) / steps * 1e3
+        kernel_ms = step(lone=True)
+        samples = W * H * spp
+        out = {"workload": "%dx%d, %d spp%s, %s%s, quality-2 synthetic maps%s, BASELINE configs[%d]" % (W, H, spp, ", progressive display every %d" % every if c["progressive"] else "", c["preset"],
+                                                                                                 " + film curve %s" % c["crf_name"] if c["crf_name"] else "", " (cloud-heavy)" if c["cloud_heavy"] else "", c["index"]),
+               "metric": metric_name(W, H, spp, c["preset"], c["cloud_heavy"], c["progressive"]),
+               "steps": steps, "ms_per_step": ms_per_step, "value": samples / (ms_per_step * 1e-3) / 1e6, "unit": "Msamples/s",
+               "kernel_ms": kernel_ms, "launches_per_step": rk.last_call_info()["launches"] * ((spp + every - 1) // every),
+               "bytes_per_sample": b_sample, "taps_r8_per_sample": n_r8,
+               "roofline_frac": (b_sample * samples / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS}
+        if my_maps is not None:
+            out.update(sparse_oracle_check(name, rk, my_maps, rk.seed))
+        return out
+    finally:
+        rk.close()
 
 
 def main():
@@ -186,7 +329,7 @@ def main():
     for k in range(max(1, args.frames_in_flight)):
         rk = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)
         if args.preset:
-            apply_preset(rk, args.preset)
+            apply_preset(rk, args.preset, args.crf_name)
         rk.set_integrator(args.integrator)
         if k == 0:
             rk.copy_textures()
@@ -338,7 +481,7 @@ def main():
                     assembled = frame.r.fetch_hdr()
                     solo = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)     # a 1-rank render of the same frame
                     if args.preset:
-                        apply_preset(solo, args.preset)
+                        apply_preset(solo, args.preset, args.crf_name)
                     solo.set_integrator(args.integrator)
                     solo.share_textures_from(r)
                     solo.accumulate(args.check_spp)
@@ -378,7 +521,7 @@ def main():
         try:
             with open(prof) as f:
                 pj = json.load(f)
-            if pj.get("workload") == "%dx%d_%dspp_q%d" % (W, H, spp, args.tex_quality) and world == 1 and not args.preset \
+            if pj.get("workload") == "%dx%d_%dspp_q%d" % (W, H, spp, args.tex_quality) and world == 1 and not args.preset and not args.cloud_heavy and args.progressive <= 0 \
                     and not args.tex_size and args.simulate_world <= 1 and args.integrator == "path_tracer":
                 # the counters belong to the kernel build that was profiled: refuse them when this run's launch duration is
                 # not the profile's (+-3 %) — a changed kernel with an unrefreshed profile must not carry stale numbers
@@ -404,7 +547,7 @@ def main():
 
     steps_per_sample = (cnt["sphere_steps"] + cnt["tracking_steps"]) / max(cnt["samples"], 1)
     out = {
-        "metric": "Msamples/sec (1920x1080, 64 spp) spectral path tracing", "value": value, "unit": "Msamples/s",
+        "metric": "Msamples/sec (1920x1080, 64 spp) spectral path tracing" if args.config_name == "cfg2" else metric_name(W, H, spp, args.preset, args.cloud_heavy, args.progressive), "value": value, "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks_seen": ranks_seen, "devices_seen": devices_seen,
@@ -412,7 +555,9 @@ def main():
         "drain_ms": my_drain_ms,
         "config": {"workload": "%dx%d, %d spp, full spectral Rayleigh+Mie+O3+clouds, quality-%d synthetic maps%s, %s, "
                                "%s" % (W, H, spp, args.tex_quality, " (%dx%d)" % tuple(args.tex_size) if args.tex_size else "",
-                                                         args.preset or "default camera", "BASELINE configs[1]" if args.integrator == "path_tracer" else "ray_marcher integrator (not the BASELINE metric)"),
+                                                         (args.preset or "default camera") + (" + film curve %s" % args.crf_name if args.crf_name else "") + (", cloud-heavy maps" if args.cloud_heavy else ""),
+                                                         "ray_marcher integrator (not the BASELINE metric)" if args.integrator != "path_tracer" else
+                                                         ("BASELINE configs[%d]" % CONFIGS[args.config_name]["index"] if args.config_name else "not a BASELINE config")),
                    "parallelism": ((("tile-partition x%d + %s reduce (%s)" if args.collective == "reduce" else "tile-partition x%d + %s gather of the owned pixels (%s)") if args.split == "tiles" else "sample-partition x%d + %s rank-ordered gather-sum (%s)") % (world, "RCCL" if backend == "nccl" else backend, args.reduce)) if world > 1
                                   else ("single GPU" if args.simulate_world <= 1 else "single GPU rendering rank 0's share of a %s partition x%d (no collective)" % (args.split, args.simulate_world)),
                    "frames_in_flight": len(frames), "launch_slots": 1 if serial else 3,
@@ -421,8 +566,10 @@ def main():
                    "kernel": timed_info["kernel"], "launches_per_call": timed_info["launches"],
                    "progressive_every": args.progressive if args.progressive > 0 else None,
                    "samples_per_step": W * H * spp},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved_gbps / HBM_PEAK_GBPS,
+        # `bound` names the roof that BINDS this kernel (VALU issue: `valu.issue` below); achieved / peak / unit / frac keep SURVEY §8(d)'s definition —
+        # algorithmic bytes over the launch's duration against the HBM peak — and `hbm_frac` repeats that fraction under its own name
+        "roofline": {"bound": "valu_issue", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved_gbps / HBM_PEAK_GBPS, "hbm_frac": achieved_gbps / HBM_PEAK_GBPS,
                      # `achieved` divides by the launch's own duration (HIP events around one frame rendered alone): the non-overlapped figure.
                      # With frames back to back the next launch fills CUs as this one drains; the same bytes over ms_per_step:
                      "frac_single_frame": achieved_gbps / HBM_PEAK_GBPS,
@@ -468,6 +615,17 @@ def main():
         out["valu"]["peak_tlaneops"] = 256 * 4 * 32 * 2.4e9 / 1e12
         out["valu"]["frac"] = out["valu"]["achieved_tlaneops"] / out["valu"]["peak_tlaneops"]
 
+    if (rank == 0 and world == 1 and args.config_name == "cfg2" and not args.no_other_configs and not args.tex_size and args.integrator == "path_tracer"
+            and args.simulate_world <= 1 and len(frames) == 1 and not serial):
+        # The other three BASELINE configs on this box, after the timed region and outside it: a few steps each (VERDICT r5 #4 — cfg3 / cfg4 / cfg5 had
+        # builder-run numbers only).  A failure of a leg is reported in its entry; it never costs the cfg2 measurement.
+        others = {}
+        for name in ("cfg3", "cfg4", "cfg5"):
+            try:
+                others[name] = run_other_config(name, r, maps, device_index)
+            except Exception as exc:          # noqa: BLE001 - reported, not swallowed
+                others[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        out["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, o = cpu_baseline(r, args, maps)
         out["cpu_baseline"] = base
@@ -523,7 +681,7 @@ def main():
             ref_hdr = frame.r.fetch_hdr() if rank == 0 else None
             lr = Renderer((W, H), (0, 1, 0), device=device_index, **tex_kw)
             if args.preset:
-                apply_preset(lr, args.preset)
+                apply_preset(lr, args.preset, args.crf_name)
             lr.set_integrator(args.integrator)
             lr.share_textures_from(r)
 

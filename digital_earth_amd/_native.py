@@ -41,7 +41,7 @@ DE_FLAG_RAY_MARCHER = 1 << 2
 DE_FLAG_AGX = 1 << 3
 DE_FLAG_FAST_MATH = 1 << 5
 
-# name -> (restype, argtypes): every symbol include/digital_earth.h declares
+# name -> (restype, argtypes): every symbol include/digital_earth.h declares (the binder's header)
 _P = ctypes.c_void_p
 SYMBOLS = {
     "de_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_P)]),
@@ -50,8 +50,6 @@ SYMBOLS = {
     "de_generate_texture": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int]),
     "de_share_textures": (ctypes.c_int, [_P, _P]),
     "de_trim_textures": (ctypes.c_int, [_P]),
-    "de_download_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint64]),
-    "de_texture_info": (ctypes.c_int, [_P, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3),
     "de_upload_luts": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int]),
     "de_set_params": (ctypes.c_int, [_P, ctypes.POINTER(DeParams)]),
     "de_get_params": (ctypes.c_int, [_P, ctypes.POINTER(DeParams)]),
@@ -59,6 +57,8 @@ SYMBOLS = {
     "de_accumulate": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]),
     "de_fetch_image": (ctypes.c_int, [_P, _P]),
     "de_fetch_image_view": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]),
+    "de_fetch_image_begin": (ctypes.c_int, [_P]),
+    "de_fetch_image_end": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]),
     "de_render_to_image": (ctypes.c_int, [_P, ctypes.POINTER(_P)]),
     "de_fetch_hdr": (ctypes.c_int, [_P, _P]),
     "de_upload_hdr": (ctypes.c_int, [_P, _P, ctypes.c_int]),
@@ -76,17 +76,26 @@ SYMBOLS = {
     "de_reduce_progressive": (ctypes.c_int, [_P, _P, ctypes.c_int]),
     "de_set_sample_partition": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     "de_reduce_ordered": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int]),
-    "de_last_reduce_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_set_display_source": (ctypes.c_int, [_P, _P]),
+    "de_synchronize": (ctypes.c_int, [_P]),
+    "de_get_tuning": (ctypes.c_int, [_P, _P]),
+    "de_set_tuning": (ctypes.c_int, [_P, _P]),
+    "de_last_error": (ctypes.c_char_p, []),
+    "de_abi_version": (ctypes.c_int, []),
+    "de_arithmetic_contract": (ctypes.c_int, []),
+}
+
+# measurement, experiment and test hooks: include/digital_earth_debug.h (same library)
+DEBUG_SYMBOLS = {
+    "de_download_texture": (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint64]),
+    "de_texture_info": (ctypes.c_int, [_P, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3),
+    "de_last_reduce_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_set_launch_slots": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     "de_set_wave_budget": (ctypes.c_int, [_P, ctypes.c_int]),
-    "de_synchronize": (ctypes.c_int, [_P]),
     "de_last_accumulate_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_get_counters": (ctypes.c_int, [_P, ctypes.POINTER(DeCounters)]),
     "de_enable_counters": (ctypes.c_int, [_P, ctypes.c_int]),
     "de_set_kernel_variant": (ctypes.c_int, [_P, ctypes.c_int]),
-    "de_get_tuning": (ctypes.c_int, [_P, _P]),
-    "de_set_tuning": (ctypes.c_int, [_P, _P]),
     "de_debug_samples": (ctypes.c_int, [_P, ctypes.c_uint64, ctypes.c_int, _P]),
     "de_debug_sched_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_set_memory_budget": (ctypes.c_int, [_P, ctypes.c_uint64]),
@@ -95,9 +104,8 @@ SYMBOLS = {
     "de_last_launch_phases": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "de_debug_v6_stats": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     "de_debug_math": (ctypes.c_int, [_P, ctypes.c_int, _P, _P, _P, ctypes.c_uint64]),
-    "de_last_error": (ctypes.c_char_p, []),
-    "de_abi_version": (ctypes.c_int, []),
-    "de_arithmetic_contract": (ctypes.c_int, []),
+    "de_debug_ordered_sum": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "de_debug_standin_reduce": (ctypes.c_int, [_P, ctypes.c_int]),
 }
 
 # entry points of the legacy library only (include/digital_earth_legacy.h): bound when present
@@ -114,7 +122,7 @@ class DeTuning(ctypes.Structure):
                 ("v6_flat_min", ctypes.c_int32), ("v6_flat_again", ctypes.c_int32), ("v6_bands", ctypes.c_int32),
                 ("v6_tail_levels", ctypes.c_int32), ("v6_tail_export", ctypes.c_int32 * 2), ("v6_tail_min_paths", ctypes.c_uint32), ("v6_tail_when_alone", ctypes.c_int32), ("v6_tail_grid", ctypes.c_int32 * 2), ("v6_stats", ctypes.c_int32),
                 ("v2_pend", ctypes.c_int32), ("v2_heavy", ctypes.c_int32), ("v2_b", ctypes.c_int32), ("v2_gas", ctypes.c_int32), ("v2_chunk", ctypes.c_int32),
-                ("v2_waves_per_cu", ctypes.c_int32), ("v2_max_spp", ctypes.c_int32), ("trace", ctypes.c_int32)]
+                ("v2_waves_per_cu", ctypes.c_int32), ("v2_max_spp", ctypes.c_int32), ("trace", ctypes.c_int32), ("v6_cu_withhold", ctypes.c_int32)]
 
 
 # Experiment overrides: the LIBRARY reads no environment variable for its tuning (de_set_tuning); this layer does, once per context, for the
@@ -129,7 +137,7 @@ ENV_TUNING = {
     "DE_V6_TAIL": ("v6_tail_levels", None), "DE_V6_TAIL_EXPORT0": ("v6_tail_export", 0), "DE_V6_TAIL_EXPORT1": ("v6_tail_export", 1),
     "DE_V6_TAIL_MIN_PATHS": ("v6_tail_min_paths", None), "DE_V6_TAIL_ALONE": ("v6_tail_when_alone", None), "DE_V6_TAIL_GRID0": ("v6_tail_grid", 0), "DE_V6_TAIL_GRID1": ("v6_tail_grid", 1),
     "DE_V2_THR": ("v2_pend", None), "DE_V2_A": ("v2_heavy", None), "DE_V2_B": ("v2_b", None), "DE_V2_G": ("v2_gas", None),
-    "DE_V2_CHUNK": ("v2_chunk", None), "DE_V2_WPC": ("v2_waves_per_cu", None), "DE_V2_MAX_SPP": ("v2_max_spp", None),
+    "DE_V6_CU_WITHHOLD": ("v6_cu_withhold", None), "DE_V2_CHUNK": ("v2_chunk", None), "DE_V2_WPC": ("v2_waves_per_cu", None), "DE_V2_MAX_SPP": ("v2_max_spp", None),
 }
 
 
@@ -154,7 +162,7 @@ def apply_env_tuning(handle):
 
 
 _lib = None
-ABI_VERSION = 5   # DE_ABI_VERSION of include/digital_earth.h
+ABI_VERSION = 6   # DE_ABI_VERSION of include/digital_earth.h
 
 
 class NativeLibraryError(RuntimeError):
@@ -179,7 +187,7 @@ def load():
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(DEBUG_SYMBOLS.items()):
         try:
             fn = getattr(L, name)
         except AttributeError:

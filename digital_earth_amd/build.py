@@ -10,7 +10,7 @@ OUT = os.path.join(_HERE, "libdigitalearth_hip.so")
 OUT_LEGACY = os.path.join(_HERE, "libdigitalearth_hip_legacy.so")
 SOURCES = ["de_api.hip", "de_fast.hip"]   # de_fast.hip: render_kernel_v6 once more, on the hardware transcendentals (DE_FLAG_FAST_MATH).  de_api.hip is one translation unit: de_api.hip -> de_rccl.h -> de_launch.h -> de_host_consts.h -> de_context.h -> the kernels
 DEPS = ["de_api.hip", "de_fast.hip", "de_rccl.h", "de_launch.h", "de_host_consts.h", "de_context.h", "render_kernel.hip", "render_kernel_v2.hip", "de_stages.h", "render_kernel_v6.hip",
-        "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h", os.path.join("..", "..", "include", "digital_earth.h")]
+        "aux_kernels.hip", "de_kernels.h", "de_device.h", "de_math.h", os.path.join("..", "..", "include", "digital_earth.h"), os.path.join("..", "..", "include", "digital_earth_debug.h")]
 DEPS_LEGACY = DEPS + [os.path.join("legacy", f) for f in ("render_kernel_v3.hip", "render_kernel_v5.hip", "de_launch_legacy.h", "de_ctx_legacy_members.inc")]
 # -ffp-contract=off is part of the arithmetic contract (de_math.h): fused operations only where written.
 # -fno-slp-vectorize: the SLP vectoriser packs pairs of scalar f32 operations into v_pk_* instructions; on gfx950 the

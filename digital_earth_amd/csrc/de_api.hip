@@ -3,6 +3,23 @@
 // de_context.h; the kernel families the product no longer runs hang in under -DDE_LEGACY_VARIANTS (legacy/).
 #include "de_rccl.h"
 
+namespace {
+// A launch slot's stream.  withhold > 0: the stream may use every CU but the LAST `withhold` of each XCD (hipExtStreamCreateWithCUMask; bit i of the mask is
+// CU i / 8 of XCD i % 8 — the driver deals the mask's bits round robin over the XCDs — so the top 8 x withhold bits are `withhold` CUs of every XCD):
+// persistent workgroups then leave those CUs to the small kernels of the context stream (collective, accumulate, display).
+hipError_t create_slot_stream(de_ctx* c, hipStream_t* out) {
+    if (c->cu_withhold <= 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    const int n = c->n_cus, keep = n - 8 * c->cu_withhold;
+    if (keep < 8) return hipErrorInvalidValue;
+    uint32_t mask[16];
+    memset(mask, 0, sizeof(mask));
+    for (int i = 0; i < keep && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)((n + 31) / 32), mask);
+}
+// CUs a render_kernel_v6 launch may fill
+int render_cus(const de_ctx* c) { return c->cu_withhold > 0 ? c->n_cus - 8 * c->cu_withhold : c->n_cus; }
+}  // namespace
+
 extern "C" {
 
 const char* de_last_error(void) { return g_err.c_str(); }
@@ -29,6 +46,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     read_legacy_env(c);       // the legacy library keeps the experiment knobs of rounds 1-4 in the environment; the product reads none (de_set_tuning)
 #endif
     memset(&c->counters, 0, sizeof(c->counters));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     size_t npx = (size_t)width * height;
     // the context stream carries the small operations between frames and the collective: highest priority, so that wave slots
     // freed by the draining render kernels of the launch slots go to them first
@@ -39,7 +57,7 @@ int de_create(int device, int width, int height, de_ctx** out) {
     {   // launch slots: launches in flight per context (de_set_launch_slots; 1 = every launch waits for the previous one)
         for (int i = 0; i < c->n_slots && e == hipSuccess; ++i) {
             LaunchSlot& s = c->slot[i];
-            e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+            e = create_slot_stream(c, &s.stream);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreate(&s.t0);
             if (e == hipSuccess) e = hipEventCreate(&s.t1);
@@ -56,7 +74,6 @@ int de_create(int device, int width, int height, de_ctx** out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_counters, DE_N_COUNTERS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(&c->d_work_counter, 16 * (DE_MAX_SLOTS + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_dens_table, (size_t)DE_DENS_TABLE_N * DE_DENS_STRIDE * sizeof(float));
-    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (e == hipSuccess) e = hipMalloc(&c->d_cie, 441 * 2 * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_srgb2spec, 900 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&c->d_o3, 441 * sizeof(float));
@@ -85,9 +102,10 @@ int de_destroy(de_ctx* c) {
     release_loan(c);
     for (auto& t : c->tex) { if (t.borrowed) continue; if (t.linear) hipFree(t.linear); if (t.packed) hipFree(t.packed); }
     if (c->luts_borrowed) { c->d_cie = nullptr; c->d_srgb2spec = nullptr; c->d_o3 = nullptr; c->d_crf = nullptr; }
-    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled, c->d_gather};
+    void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled, c->d_gather, c->d_standin};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
+    for (int k = 0; k < 2; ++k) { if (c->h_ring[k]) hipHostFree(c->h_ring[k]); if (c->ev_ring[k]) hipEventDestroy(c->ev_ring[k]); }
     if (c->h_issued) hipHostFree(c->h_issued);
 #ifdef DE_LEGACY_VARIANTS
     legacy_destroy(c);
@@ -411,6 +429,37 @@ int de_fetch_image_view(de_ctx* c, const float** host_image) {
     return frame_status(c);
 }
 
+/* The window loop pipelined (include/digital_earth.h).  begin: the display transform of the frame as it stands and its copy into one of two pinned
+ * buffers are ENQUEUED on the context stream (which waits, on the device, for the launches issued so far); the host returns at once and may issue the
+ * next frame's de_accumulate — its render launch runs beside the display and the copy.  end: wait for the oldest fetch begun and hand out its image. */
+int de_fetch_image_begin(de_ctx* c) {
+    if (!c) return fail(DE_ERR_INVALID, "null context");
+    if (c->fetch_begun - c->fetch_ended >= 2u) return fail(DE_ERR_STATE, "two fetches are in flight already: de_fetch_image_end first");
+    const int k = (int)(c->fetch_begun & 1u);
+    const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->h_ring[k]) {
+        if (hipHostMalloc((void**)&c->h_ring[k], bytes, hipHostMallocDefault) != hipSuccess) { c->h_ring[k] = nullptr; (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no pinned host memory for the staging buffers"); }
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_ring[k], hipEventDisableTiming));
+    }
+    int rc = de_render_to_image(c, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_ring[k], c->d_image, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_ring[k], c->stream));
+    c->fetch_begun++;
+    return DE_OK;
+}
+int de_fetch_image_end(de_ctx* c, const float** host_image) {
+    if (!c || !host_image) return fail(DE_ERR_INVALID, "null argument");
+    if (c->fetch_begun == c->fetch_ended) return fail(DE_ERR_STATE, "no fetch in flight: de_fetch_image_begin first");
+    const int k = (int)(c->fetch_ended & 1u);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_ring[k]));
+    c->fetch_ended++;
+    *host_image = c->h_ring[k];
+    return frame_status(c);
+}
+
 int de_fetch_hdr(de_ctx* c, float* out) {
     if (!c || !out) return fail(DE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -487,6 +536,7 @@ int de_synchronize(de_ctx* c) {
 }
 int de_last_accumulate_ms(de_ctx* c, float* ms) {
     if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
+    if (c->timing_empty) { *ms = 0.0f; return DE_OK; }      // the last call's share was empty: nothing was launched
     if (!c->timing_valid) return fail(DE_ERR_STATE, "no de_accumulate has been issued");
     HIP_TRY(hipSetDevice(c->device));
     // from the start of the call's first launch (after its waits) to the end of its last accumulate_kernel
@@ -521,6 +571,7 @@ int de_get_tuning(de_ctx* c, de_tuning* t) {
     t->v2_pend = c->tune_pend; t->v2_heavy = c->tune_heavy; t->v2_b = c->tune_b; t->v2_gas = c->tune_gas; t->v2_chunk = c->tune_chunk;
     t->v2_waves_per_cu = c->tune_wpc; t->v2_max_spp = c->tune_max_spp;
     t->trace = c->trace ? 1 : 0;
+    t->v6_cu_withhold = c->cu_withhold;
     return DE_OK;
 }
 int de_set_tuning(de_ctx* c, const de_tuning* t) {
@@ -531,8 +582,23 @@ int de_set_tuning(de_ctx* c, const de_tuning* t) {
     for (int k = 0; k < 3; ++k) if (t->v6_service_lanes[k] < 1 || t->v6_service_lanes[k] > 64 || t->v6_service_area[k] < 0) return fail(DE_ERR_INVALID, "service thresholds out of range");
     if (t->v6_tail_levels < 0 || t->v6_tail_levels > 2) return fail(DE_ERR_INVALID, "v6_tail_levels must be 0..2");
     for (int k = 0; k < 2; ++k) if (t->v6_tail_export[k] < 1 || t->v6_tail_export[k] > 1024 || t->v6_tail_grid[k] < 1 || t->v6_tail_grid[k] > 4096) return fail(DE_ERR_INVALID, "tail settings out of range");
+    if (t->v6_cu_withhold < 0 || 8 * t->v6_cu_withhold > c->n_cus - 8) return fail(DE_ERR_INVALID, "v6_cu_withhold: CUs per XCD withheld from the render streams, 0 .. (CUs / 8 - 1)");
     int rc = de_set_kernel_variant(c, t->kernel_variant);
     if (rc) return rc;
+    if (t->v6_cu_withhold != c->cu_withhold) {
+        // the launch slots' streams carry the mask: make them again (nothing may be in flight on them)
+        HIP_TRY(hipSetDevice(c->device));
+        rc = sync_all(c);
+        if (rc) return rc;
+        c->cu_withhold = t->v6_cu_withhold;
+        for (int i = 0; i < DE_MAX_SLOTS; ++i) {
+            LaunchSlot& sl = c->slot[i];
+            if (!sl.stream) continue;
+            HIP_TRY(hipStreamDestroy(sl.stream));
+            sl.stream = nullptr;
+            HIP_TRY(create_slot_stream(c, &sl.stream));
+        }
+    }
     if (t->launch_slots != c->n_slots || t->big_launch_slots != c->big_slots) { rc = de_set_launch_slots(c, t->launch_slots, t->big_launch_slots); if (rc) return rc; }
     c->auto_v6_min_items = (unsigned long long)t->v6_min_paths;
     for (int k = 0; k < 3; ++k) { c->v6_svc_area[k] = t->v6_service_area[k]; c->v6_svc[k] = t->v6_service_lanes[k]; }
@@ -573,13 +639,13 @@ int de_set_launch_slots(de_ctx* c, int n_slots, int n_big) {
     for (int i = c->n_slots; i < n_slots; ++i) {          // slots that did not exist yet
         LaunchSlot& s = c->slot[i];
         if (s.stream) continue;
-        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIP_TRY(create_slot_stream(c, &s.stream));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&s.t0));
         HIP_TRY(hipEventCreate(&s.t1));
     }
     c->n_slots = n_slots; c->big_slots = n_big;
-    c->next_slot = 0; c->last_slot = -1;
+    c->next_slot = 0; c->last_slot = -1; c->last_v6_slot = -1;
     return DE_OK;
 }
 int de_set_wave_budget(de_ctx* c, int waves_per_cu) {

@@ -75,10 +75,15 @@ struct de_ctx {
     // the slots lazily (join_slots) before anything that reads or writes the HDR buffer or rewrites what a launch reads.
     LaunchSlot slot[DE_MAX_SLOTS];
     int n_slots = 8, big_slots = 3, next_slot = 0, last_slot = -1;   // launches with > 96 MB of records cycle through the first big_slots only
+    int last_v6_slot = -1;          // the slot of the newest render_kernel_v6 launch (the tail's "has a successor on another slot" word is about v6 launches only)
+    int cu_withhold = 0;            // de_tuning.v6_cu_withhold: CUs per XCD the launch slots' streams may NOT use (hipExtStreamCreateWithCUMask), so that small kernels of
+                                    // the context stream (collective, accumulate, display) find a free CU while persistent workgroups own the others; 0 = plain streams
+    float* d_standin = nullptr;     // second operand of de_debug_standin_reduce (zeros, [H][W][3])
     hipEvent_t ev_main = nullptr;   // last state of the context stream the slots may have to wait for
     uint64_t gen_render = 1, gen_hdr = 1, rec_render = 0, rec_hdr = 0;   // generations of context-stream work that launches depend on
     int t0_slot = -1, t1_slot = -1;
     bool timing_valid = false;
+    bool timing_empty = false;      // the last de_accumulate launched nothing (an empty share): its duration is 0, not the previous call's
     DevTexture tex[DE_TEX_COUNT];
     float* d_cie = nullptr;      // 441 x 2 x 3 (f16-quantised)
     float* d_srgb2spec = nullptr;
@@ -95,6 +100,11 @@ struct de_ctx {
     float* d_image = nullptr;    // (W, H, 3)
     float* d_scratch = nullptr;  // (W, H, 3) / debug [H][W][4]
     float* h_stage = nullptr;     // pinned host staging for fetch_image / fetch_hdr (a pageable destination copies at a fraction of the link rate)
+    // de_fetch_image_begin / _end: the window loop pipelined — display + device-to-host copy of frame k run on the context stream while launch k + 1 renders.
+    // Two pinned buffers, two events; fetch_begun / fetch_ended count the calls (begun - ended = fetches in flight, at most 2).
+    float* h_ring[2] = {nullptr, nullptr};
+    hipEvent_t ev_ring[2] = {nullptr, nullptr};
+    unsigned fetch_begun = 0, fetch_ended = 0;
     uint32_t* d_tiles = nullptr;
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;
     unsigned long long* d_counters = nullptr;

@@ -1,7 +1,7 @@
 // de_kernels.h — device structures shared by the kernels and the host API (de_api.hip).
 #pragma once
 #include "de_device.h"
-#include "../../include/digital_earth.h"
+#include "../../include/digital_earth_debug.h"      // includes digital_earth.h: the library defines every entry point of both headers
 
 // Per-frame constants: everything the reference recomputes per pixel (or per launch) from scalar state that is
 // uniform over the image.  Filled ON THE DEVICE by setup_kernel with the contract arithmetic, so the values are the

@@ -175,13 +175,15 @@ void legacy_note_abort(de_ctx* c);
 #endif
 
 // render_kernel_v6: buffers of one launch slot (independent of the launch's size)
-int v6_reserve(de_ctx* c, int idx, hipStream_t stream) {
+int v6_reserve(de_ctx* c, int idx, hipStream_t stream, unsigned long long n_items) {
     de_ctx::V6State& S = c->v6s[idx];
-    const uint32_t n_wg = (uint32_t)c->n_cus * DE_V6_WG_PER_CU;
-    // the tail's pools: level k exports at most (workgroups of level k) x v6_tail_export[k] records (render_kernel_v6.hip: "The tail")
+    const uint32_t n_wg = (uint32_t)(c->cu_withhold > 0 ? c->n_cus - 8 * c->cu_withhold : c->n_cus) * DE_V6_WG_PER_CU;
+    // the tail's pools: level k exports at most (workgroups of level k) x v6_tail_export[k] records (render_kernel_v6.hip: "The tail").  Only a launch that can have
+    // a tail needs them: the interactive 1-spp pattern (all 8 launch slots, calls far below v6_tail_min_paths) holds none
     uint32_t want[2] = {0u, 0u};
-    if (c->v6_tail_levels >= 1) want[0] = n_wg * (uint32_t)c->v6_tail_export[0];
-    if (c->v6_tail_levels >= 2) want[1] = std::min((uint32_t)c->v6_tail_grid[0], n_wg) * (uint32_t)c->v6_tail_export[1];
+    const bool tail = n_items >= (unsigned long long)c->v6_tail_min_paths;
+    if (tail && c->v6_tail_levels >= 1) want[0] = n_wg * (uint32_t)c->v6_tail_export[0];
+    if (tail && c->v6_tail_levels >= 2) want[1] = std::min((uint32_t)c->v6_tail_grid[0], n_wg) * (uint32_t)c->v6_tail_export[1];
     for (int k = 0; k < 2; ++k) {
         if (S.pool_cap[k] >= want[k]) continue;
         HIP_TRY(hipStreamSynchronize(stream));
@@ -238,8 +240,10 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     if (e != hipSuccess) return e;
     // This launch's number.  The word the kernels read holds the number of the newest launch that HAS A SUCCESSOR ON ANOTHER STREAM: written here, when that
     // successor is issued (a successor on the same launch slot waits for the whole chain anyway: exporting would only add the tail launch's latency)
+    // (the slot of the newest render_kernel_v6 launch, not of the newest launch of any kernel: a state-machine call in between is no successor — ADVICE r5)
     const uint32_t seq = ++c->v6_launch_seq;
-    if (c->last_slot >= 0 && c->last_slot != idx) __atomic_store_n(c->h_issued, seq - 1u, __ATOMIC_RELEASE);
+    if (c->last_v6_slot >= 0 && c->last_v6_slot != idx) __atomic_store_n(c->h_issued, seq - 1u, __ATOMIC_RELEASE);
+    c->last_v6_slot = idx;
     A.issued = d_issued; A.seq = c->v6_tail_when_alone ? 0xffffffffu : seq;      // (4 Mi paths by default: launches that fill the GPU several times over)
     const bool fast = (c->p.flags & DE_FLAG_FAST_MATH) != 0u;
     for (int l = 0; l <= levels; ++l) {
@@ -397,6 +401,7 @@ int accumulate_default(de_ctx* c, RenderArgs& a, int spp, int first_index) {
     }
     bool first = true;
     c->last_call[0] = 0; c->last_call[1] = 1; c->last_call[2] = 0; c->last_call[3] = 0;
+    c->timing_empty = true;       // a call that launches nothing (an empty share of a sample partition) has no duration: de_last_accumulate_ms says so instead of repeating the previous call's
     for (int done = 0; done < spp && a.n_tiles > 0;) {
         const int n = (spp - done < max_spp) ? spp - done : max_spp;
         // small launches (the interactive 1-spp pattern) use all the slots; big ones only the first few — each slot keeps a record buffer of
@@ -407,7 +412,7 @@ int accumulate_default(de_ctx* c, RenderArgs& a, int spp, int first_index) {
         const int si = c->next_slot % n_cycle;
         c->launch_slot = si;
         LaunchSlot& s = c->slot[si];
-        if (v6k) { int rc6 = v6_reserve(c, si, s.stream); if (rc6) return rc6; }
+        if (v6k) { int rc6 = v6_reserve(c, si, s.stream, (unsigned long long)a.n_tiles * 64ull * (unsigned long long)n); if (rc6) return rc6; }
         c->launch_variant = v6k ? 6 : 2;
         if (need > s.contrib_items) {
             // grow the record buffers of EVERY slot of this launch's cycle now: the first launch of a new size pays for all the
@@ -450,7 +455,7 @@ int accumulate_default(de_ctx* c, RenderArgs& a, int spp, int first_index) {
         c->last_slot = si;
         c->next_slot = (si + 1) % n_cycle;
         done += n;
-        if (done >= spp) { HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true; }
+        if (done >= spp) { HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true; c->timing_empty = false; }
     }
     return DE_OK;
 }

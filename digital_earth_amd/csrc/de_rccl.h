@@ -149,6 +149,30 @@ namespace {
 // is part of the result.  ncclReduce leaves that order to the algorithm RCCL picks; here the ranks' buffers are GATHERED on the root (one
 // ncclSend / ncclRecv pair per peer in one group: the root's ingress runs over its xGMI links in parallel) and added by ordered_sum_kernel
 // in rank order, so the assembled frame is a function of the partition alone (tests hold it to the oracle's partial sums added the same way).
+// the root's buffers: one slot of W*H*3 floats per rank (the root's own stays unused: its part is read in place), the assembled frame when out of place
+int ordered_root_buffers(de_ctx* c, int world, bool out_of_place) {
+    const size_t count = (size_t)c->W * c->H * 3;
+    if (c->gather_world < world) {
+        { int rc2 = sync_all(c); if (rc2) return rc2; }
+        if (c->d_gather) hipFree(c->d_gather);
+        c->d_gather = nullptr; c->gather_world = 0;
+        if (hipMalloc(&c->d_gather, (size_t)world * count * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no room for the gather buffer of de_reduce_ordered"); }
+        c->gather_world = world;
+    }
+    if (out_of_place && !c->d_assembled) HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
+    return DE_OK;
+}
+// the root's sum, on the context stream: part r = rank r's gathered buffer, the root's own accumulation buffer in place
+int launch_ordered_sum(de_ctx* c, int world, int root, bool out_of_place) {
+    const size_t count = (size_t)c->W * c->H * 3;
+    OrderedSumArgs o;
+    for (int r = 0; r < world; ++r) o.part[r] = (r == root) ? c->d_hdr : c->d_gather + (size_t)r * count;
+    o.out = out_of_place ? c->d_assembled : c->d_hdr; o.n_parts = world; o.n4 = count / 4; o.n = count;
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
+    HIP_TRY(hipGetLastError());
+    if (out_of_place) c->display_src = c->d_assembled;
+    return DE_OK;
+}
 int reduce_ordered_impl(de_ctx* c, void* comm, int root, bool out_of_place) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
     void* use = comm ? comm : c->comm;
@@ -171,28 +195,14 @@ int reduce_ordered_impl(de_ctx* c, void* comm, int root, bool out_of_place) {
     if (rc) return rc;
     const size_t count = (size_t)c->W * c->H * 3;
     if (!c->ev_r0) { HIP_TRY(hipEventCreate(&c->ev_r0)); HIP_TRY(hipEventCreate(&c->ev_r1)); }
-    if (my_rank == root) {
-        if (c->gather_world < world) {
-            { int rc2 = sync_all(c); if (rc2) return rc2; }
-            if (c->d_gather) hipFree(c->d_gather);
-            c->d_gather = nullptr; c->gather_world = 0;
-            if (hipMalloc(&c->d_gather, (size_t)world * count * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return fail(DE_ERR_NOMEM, "no room for the gather buffer of de_reduce_ordered"); }
-            c->gather_world = world;
-        }
-        if (out_of_place && !c->d_assembled) HIP_TRY(hipMalloc(&c->d_assembled, count * sizeof(float)));
-    }
+    if (my_rank == root) { int rc2 = ordered_root_buffers(c, world, out_of_place); if (rc2) return rc2; }
     HIP_TRY(hipEventRecord(c->ev_r0, c->stream));
     if (my_rank == root) {
         RCCL_TRY(g_rccl.GroupStart());
         for (int r = 0; r < world; ++r)
             if (r != root) { int e = g_rccl.Recv(c->d_gather + (size_t)r * count, count, /*ncclFloat32*/ 7, r, use, c->stream); if (e != 0) { g_rccl.GroupEnd(); return fail(DE_ERR_HIP, std::string("ncclRecv: ") + g_rccl.GetErrorString(e)); } }
         RCCL_TRY(g_rccl.GroupEnd());
-        OrderedSumArgs o;
-        for (int r = 0; r < world; ++r) o.part[r] = (r == root) ? c->d_hdr : c->d_gather + (size_t)r * count;
-        o.out = out_of_place ? c->d_assembled : c->d_hdr; o.n_parts = world; o.n4 = count / 4; o.n = count;
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
-        HIP_TRY(hipGetLastError());
-        if (out_of_place) c->display_src = c->d_assembled;
+        { int rc2 = launch_ordered_sum(c, world, root, out_of_place); if (rc2) return rc2; }
     } else {
         RCCL_TRY(g_rccl.Send(c->d_hdr, count, /*ncclFloat32*/ 7, root, use, c->stream));
     }
@@ -203,6 +213,53 @@ int reduce_ordered_impl(de_ctx* c, void* comm, int root, bool out_of_place) {
 }
 }  // namespace
 int de_reduce_ordered(de_ctx* c, void* comm, int root, int out_of_place) { return reduce_ordered_impl(c, comm, root, out_of_place != 0); }
+
+/* include/digital_earth_debug.h: the root's half of de_reduce_ordered with the parts coming from the host instead of ncclRecv */
+int de_debug_ordered_sum(de_ctx* c, const float* parts, int n_parts, int root, int out_of_place, float* out) {
+    if (!c || !parts || !out || n_parts < 2 || n_parts > 16 || root < 0 || root >= n_parts) return fail(DE_ERR_INVALID, "de_debug_ordered_sum: 2..16 parts, 0 <= root < n_parts");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = join_slots(c);
+    if (rc) return rc;
+    rc = ordered_root_buffers(c, n_parts, out_of_place != 0);
+    if (rc) return rc;
+    const size_t count = (size_t)c->W * c->H * 3;
+    touched_hdr(c);
+    for (int r = 0; r < n_parts; ++r)
+        HIP_TRY(hipMemcpyAsync(r == root ? c->d_hdr : c->d_gather + (size_t)r * count, parts + (size_t)r * count, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = launch_ordered_sum(c, n_parts, root, out_of_place != 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, out_of_place ? c->d_assembled : c->d_hdr, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+/* include/digital_earth_debug.h: a one-GPU stand-in for the frame's collective, where de_reduce goes on the context stream */
+int de_debug_standin_reduce(de_ctx* c, int extra_copies) {
+    if (!c || extra_copies < 0 || extra_copies > 15) return fail(DE_ERR_INVALID, "de_debug_standin_reduce: 0..15 extra copies");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = join_slots(c);
+    if (rc) return rc;
+    rc = frame_status(c);
+    if (rc) return rc;
+    const size_t count = (size_t)c->W * c->H * 3;
+    if (!c->d_standin) {
+        HIP_TRY(hipMalloc(&c->d_standin, count * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->d_standin, 0, count * sizeof(float), c->stream));
+    }
+    rc = ordered_root_buffers(c, extra_copies > 0 ? 2 : 1, true);
+    if (rc) return rc;
+    if (!c->ev_r0) { HIP_TRY(hipEventCreate(&c->ev_r0)); HIP_TRY(hipEventCreate(&c->ev_r1)); }
+    HIP_TRY(hipEventRecord(c->ev_r0, c->stream));
+    for (int k = 0; k < extra_copies; ++k) HIP_TRY(hipMemcpyAsync(c->d_gather, c->d_standin, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    OrderedSumArgs o;
+    o.part[0] = c->d_hdr; o.part[1] = c->d_standin; o.out = c->d_assembled; o.n_parts = 2; o.n4 = count / 4; o.n = count;
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
+    c->reduce_timing_valid = true;
+    touched_hdr(c);                        // it READS d_hdr, like the collective: the next accumulate_kernel is ordered after it
+    return DE_OK;
+}
 
 int de_reduce(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, false); }
 int de_reduce_progressive(de_ctx* c, void* comm, int root) { return reduce_impl(c, comm, root, true); }

@@ -452,6 +452,7 @@ int accumulate_legacy(de_ctx* c, RenderArgs& a, int spp, int first_index) {
     }
     bool first = true;
     c->last_call[0] = 0; c->last_call[1] = 1; c->last_call[2] = 0; c->last_call[3] = 0;
+    c->timing_empty = true;
     for (int done = 0; done < spp && a.n_tiles > 0;) {
         bool this_v3 = v3k;
         int n = (spp - done < max_spp) ? spp - done : max_spp;
@@ -467,7 +468,7 @@ int accumulate_legacy(de_ctx* c, RenderArgs& a, int spp, int first_index) {
         const int pipe = (v3k && pipes >= 2) ? si : 0;
         c->launch_pipe = pipe; c->launch_pipes = n_cycle; c->launch_slot = si;
         if (v5k) { int rc5 = v5_reserve(c, si, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
-        if (v6k) { int rc6 = v6_reserve(c, si, c->slot[si].stream); if (rc6) return rc6; }
+        if (v6k) { int rc6 = v6_reserve(c, si, c->slot[si].stream, (unsigned long long)a.n_tiles * 64ull * (unsigned long long)n); if (rc6) return rc6; }
         if (this_v3 && c->v3_finisher == 5 && c->launch_depths < 25) { int rc5 = v5_reserve(c, DE_MAX_SLOTS + pipe, c->slot[si].stream, (size_t)a.n_tiles * 64u * (size_t)n); if (rc5) return rc5; }
         if (this_v3) {
             // queues for this batch; when the device has no room for them the batch shrinks (split launches give the same bits),
@@ -533,7 +534,7 @@ int accumulate_legacy(de_ctx* c, RenderArgs& a, int spp, int first_index) {
         c->next_slot = (si + 1) % n_cycle;
         done += n;
         if (done >= spp) {
-            HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true;
+            HIP_TRY(hipEventRecord(s.t1, s.stream)); c->t1_slot = si; c->timing_valid = true; c->timing_empty = false;
         }
     }
     return DE_OK;

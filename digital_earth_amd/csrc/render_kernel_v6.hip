@@ -405,13 +405,17 @@ struct Wave {
             if (STATS && !primary_left) drain_sample((uint32_t)((int)DE_V6_P - free_slots));
             if (A.export_at != 0u && !primary_left) {
                 // the tail: nothing left to start and few paths alive — from here on this workgroup only exports (see "The tail")
-                const uint32_t live = DE_V6_P - (uint32_t)free_slots;
+                uint32_t live = DE_V6_P - (uint32_t)free_slots;
                 // (only once EVERY wave of the workgroup knows that nothing is left to start — a wave may hold the rest of a 256-item claim while it works in a
                 // stage: from then on the population can only fall, so a workgroup exports at most export_at records and the pool cannot overflow)
                 uint32_t two = 0;
                 if (lane_id() < 2) two = ld_wg(cw + 18 + lane_id());
                 bool exporting = __builtin_amdgcn_readlane((int)two, 0) != 0;
                 const bool starters = __builtin_amdgcn_readlane((int)two, 1) != 0;
+                // (`ready` was read BEFORE the starters word: a wave that started 64 more paths and gave up its starter's role between the two reads would leave
+                // `live` too small and the workgroup could export more than export_at records — the bound the pool is sized by.  Once no starter is left the
+                // population only falls: the free ring read again AFTER that observation is an upper bound for good.  ADVICE r5)
+                if (!exporting && !starters) live = DE_V6_P - uni(ld_wg(tail(Q_FREE)) - ld_wg(head(Q_FREE)));
                 if (!exporting && !starters && live != 0u && live <= A.export_at) {
                     // Export only if another launch of this context is queued behind this one: the slots this workgroup frees are then taken at once, which is
                     // what the chain is for; a launch with nothing behind it (a frame rendered alone, the last call before a fetch) would only end later for it —

@@ -212,7 +212,7 @@ class EarthViewer:
         self._image = self.renderer.fetch_image()
         return self._image
 
-    def frame(self, spp=1, copy=True, **sliders):
+    def frame(self, spp=1, copy=True, pipelined=False, **sliders):
         """ONE iteration of the reference's window loop (earth_viewer.py:203-317), with the GUI sliders passed as keywords
         (sun_angle, sun_path_rot, fov, aspect_scale, exposure, selected_crf, gamma):
           1. a moved camera is pushed to the renderer and marks the framebuffer for reset          (:206-213)
@@ -220,7 +220,10 @@ class EarthViewer:
           3. slider changes: sun angle / sun path rotation / fov / aspect scale mark the framebuffer for reset;
              exposure, camera response and gamma do not (display-only)                            (:268-305)
           4. the scalars are written to the renderer, then the reset happens                       (:308-317)
-        Returns the displayed image of step 2 (copy=False: a read-only view that the next frame() overwrites — what a canvas needs)."""
+        Returns the displayed image of step 2 (copy=False: a read-only view that the next frame() overwrites — what a canvas needs).
+        pipelined=True: the display and the host copy of this frame are only enqueued (Renderer.fetch_image(lag=1)) and the image RETURNED is the
+        previous iteration's (None in the first): the next iteration's accumulate() renders while this frame is shown — the same images, one
+        iteration later, at a fraction of the frame time; finish() returns the last one."""
         r = self.renderer
         should_reset = False
         if self.camera.update_camera(0.0):
@@ -229,7 +232,7 @@ class EarthViewer:
             r.set_up(*self.camera._up)
             should_reset = True
         r.accumulate(int(spp))                  # == accumulate() x spp, bit for bit
-        self._image = r.fetch_image(copy=copy)
+        self._image = r.fetch_image(copy=copy, lag=1 if pipelined else 0)
         if self._sliders is None:               # current_* of earth_viewer.py:191-199, read once when the loop starts
             self._sliders = {"sun_angle": r.sun_angle[None], "sun_path_rot": r.sun_path_rot[None], "fov": r.fov[None],
                              "aspect_scale": r.aspect_scale[None], "exposure": r.exposure[None],
@@ -248,6 +251,13 @@ class EarthViewer:
         if should_reset:
             r.reset_framebuffer()
         return self._image
+
+    def finish(self, copy=True):
+        """End a pipelined loop: the image of the last frame() iteration (None when nothing is in flight)."""
+        img = self.renderer.fetch_pending(copy=copy)
+        if img is not None:
+            self._image = img
+        return img
 
     def close(self):
         """Release the renderer.  A zero-copy image kept from frame(copy=False) is copied first: it lives in the renderer's staging buffer."""

@@ -234,6 +234,13 @@ class Renderer:
                                        crf.shape[1]))
         self._textures_copied = True
 
+    def copy_texture(self, slot):
+        """Send ONE map of this renderer's own texture plan to the device.  After share_textures_from() this makes the renderer the owner
+        of that map while it keeps borrowing the others (a second view of the same Earth under another cloud cover: BASELINE cfg4's
+        cloud-heavy variant differs from the default in the cloud map alone)."""
+        self._copy_one(self._texture_plan[slot])
+        self._own_slots = getattr(self, "_own_slots", set()) | {int(slot)}
+
     def share_textures_from(self, other):
         """Use `other`'s device-resident maps and LUTs (same GPU) instead of uploading / generating copies: a second
         frame in flight costs no second 9 GB.  Keeps a reference to `other` so it outlives this renderer."""
@@ -241,6 +248,7 @@ class Renderer:
             other.copy_textures()
         check(self._lib.de_share_textures(self._h, other._h))
         self._lender = other
+        self._own_slots = set()
         self._textures_copied = True
 
     def trim_textures(self):
@@ -251,7 +259,7 @@ class Renderer:
 
     def download_texture(self, slot):
         """The map as uploaded.  A borrower (share_textures_from) holds no as-uploaded copy: the owner's is returned."""
-        if getattr(self, "_lender", None) is not None:
+        if getattr(self, "_lender", None) is not None and int(slot) not in getattr(self, "_own_slots", ()):
             return self._lender.download_texture(slot)
         w, h, ch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.de_texture_info(self._h, slot, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)))
@@ -380,23 +388,55 @@ class Renderer:
         check(self._lib.de_accumulate(self._h, int(spp), self.seed, self.tile_rank, self.tile_world))
         self.current_spp += int(spp)
 
-    def fetch_image(self, copy=True):
+    def _staging_view(self, ptr):
+        view = np.ctypeslib.as_array(ptr, shape=(self.image_res[0], self.image_res[1], 3)).view(_StagingView)
+        view.flags.writeable = False
+        view._owner = self                      # the memory belongs to the context: the view keeps its Renderer alive ...
+        self._view_ref = weakref.ref(view)      # ... and close() refuses while the view is
+        return view
+
+    def fetch_image(self, copy=True, lag=0):
         """renderer.py:382-384 — display transform of the accumulation; (W, H, 3) float32 in [0, 1].  copy=False returns a read-only
         view of the library's pinned staging buffer, valid until the next fetch_* call on this renderer (what a window loop needs: it
-        hands the image to the canvas before it renders again) — no 24.9 MB host copy, no fresh pages."""
+        hands the image to the canvas before it renders again) — no 24.9 MB host copy, no fresh pages.
+
+        lag=1: the window loop PIPELINED (de_fetch_image_begin / _end).  The display transform and the device-to-host copy of the frame as it
+        stands are only ENQUEUED; the call returns the image of the PREVIOUS lag=1 call (None the first time), so the caller's next
+        accumulate() renders while this frame is displayed and copied.  Every image equals what the synchronous loop returns for the same
+        frame, bit for bit, one call later; fetch_pending() hands out the last one."""
         if not self._textures_copied:
             self.copy_textures()
+        if lag not in (0, 1):
+            raise ValueError("lag must be 0 or 1")
+        if lag:
+            check(self._lib.de_fetch_image_begin(self._h))
+            self._fetches = getattr(self, "_fetches", 0) + 1
+            if self._fetches < 2:
+                return None
+            return self._fetch_end(copy)
+        if getattr(self, "_fetches", 0):
+            raise RuntimeError("lagged fetches are in flight: fetch_pending() first")
         if not copy:
             ptr = ctypes.POINTER(ctypes.c_float)()
             check(self._lib.de_fetch_image_view(self._h, ctypes.byref(ptr)))
-            view = np.ctypeslib.as_array(ptr, shape=(self.image_res[0], self.image_res[1], 3)).view(_StagingView)
-            view.flags.writeable = False
-            view._owner = self                      # the memory belongs to the context: the view keeps its Renderer alive ...
-            self._view_ref = weakref.ref(view)      # ... and close() refuses while the view is
-            return view
+            return self._staging_view(ptr)
         out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
         check(self._lib.de_fetch_image(self._h, out.ctypes.data))
         return out
+
+    def _fetch_end(self, copy):
+        ptr = ctypes.POINTER(ctypes.c_float)()
+        self._fetches -= 1
+        check(self._lib.de_fetch_image_end(self._h, ctypes.byref(ptr)))
+        view = self._staging_view(ptr)
+        return np.array(view) if copy else view
+
+    def fetch_pending(self, copy=True):
+        """End the pipelined window loop: wait for the fetches still in flight and return the newest image (None when there is none)."""
+        img = None
+        while getattr(self, "_fetches", 0) > 0:
+            img = self._fetch_end(copy)
+        return img
 
     def fetch_hdr(self):
         out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)
@@ -526,6 +566,23 @@ class Renderer:
         ms = ctypes.c_float()
         check(self._lib.de_last_reduce_ms(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def debug_ordered_sum(self, parts, root=0, out_of_place=False):
+        """The root's half of reduce_ordered on ONE GPU (include/digital_earth_debug.h): `parts` = per-rank partial sums as (W, H, 3) arrays; part `root`
+        is loaded into the accumulation buffer, the others where ncclRecv would put them; the library's own launch adds them in rank order.
+        Returns the assembled frame as (W, H, 3)."""
+        W, H = self.image_res
+        dev = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float32).transpose(1, 0, 2) for p in parts]))      # device layout [H][W][3]
+        if dev.shape != (len(parts), H, W, 3):
+            raise ValueError("every part must have shape (W, H, 3)")
+        out = np.empty((H, W, 3), dtype=np.float32)
+        check(self._lib.de_debug_ordered_sum(self._h, dev.ctypes.data, len(parts), int(root), 1 if out_of_place else 0, out.ctypes.data))
+        return np.ascontiguousarray(out.transpose(1, 0, 2))
+
+    def debug_standin_reduce(self, extra_copies=0):
+        """A one-GPU stand-in for the frame's collective, enqueued where reduce() goes (include/digital_earth_debug.h); last_reduce_ms() then
+        reports its queue-to-finish latency."""
+        check(self._lib.de_debug_standin_reduce(self._h, int(extra_copies)))
 
     def set_display_source(self, device_ptr):
         """Display / fetch from another [H][W][3] f32 device buffer (None: the accumulation buffer again)."""

@@ -28,8 +28,11 @@ extern "C" {
  * loans recorded by de_share_textures.  4: additions only — de_set_memory_budget / de_get_memory_use, de_last_call_info, de_fetch_image_view, de_debug_v5_stats, de_debug_v6_stats,
  * kernel variants 5 and 6.  5 (round 5): de_set_tuning / de_get_tuning replace every environment variable the library used to read for its
  * tuning; de_set_sample_partition, de_reduce_ordered, de_last_launch_phases added; kernel variants 1, 3 and 5 and de_debug_v5_stats moved to the
- * legacy library (digital_earth_legacy.h); an abort of a persistent launch is sticky until de_reset. */
-#define DE_ABI_VERSION 5
+ * legacy library (digital_earth_legacy.h); an abort of a persistent launch is sticky until de_reset.  6 (round 6): the measurement, experiment and test hooks
+ * (timers, counters, statistics, de_debug_*, map read-back, de_set_kernel_variant / _launch_slots / _wave_budget / _memory_budget) are declared in
+ * digital_earth_debug.h — still exported, no longer in the binder's header; de_fetch_image_begin / _end (the window loop pipelined), de_tuning.v6_cu_withhold,
+ * de_debug_ordered_sum, de_debug_standin_reduce added. */
+#define DE_ABI_VERSION 6
 /* version of the arithmetic contract the kernels and the oracle implement: golden vectors are tied to it */
 #define DE_ARITHMETIC_CONTRACT 2
 
@@ -89,17 +92,6 @@ typedef struct de_params {
     int32_t reserved[7];
 } de_params;
 
-/* work counters of the last de_accumulate calls since de_reset (algorithmic bytes per sample) */
-typedef struct de_counters {
-    uint64_t samples;          /* paths traced */
-    uint64_t taps_r8;          /* bilinear taps of single-channel maps (4 texels = 4 B each) */
-    uint64_t taps_rgb8;        /* bilinear taps of colour maps (4 texels, 16 B each as rgba8 in the reference) */
-    uint64_t sphere_steps;     /* intersect_land iterations (pathtracer.py:37-44) */
-    uint64_t tracking_steps;   /* delta + ratio tracking iterations (pathtracer.py:91-112,130-141) */
-    uint64_t vertices;         /* path vertices (pathtracer.py:349) */
-    uint64_t rng_draws;
-    uint64_t reserved[9];
-} de_counters;
 
 typedef struct de_ctx de_ctx;
 
@@ -124,9 +116,6 @@ int de_share_textures(de_ctx* dst, de_ctx* src);
  * Afterwards de_download_texture and a change of the sampler address mode fail with DE_ERR_STATE until the maps are
  * uploaded or generated again. */
 int de_trim_textures(de_ctx* ctx);
-/* Read a map back as uploaded (row-major, `channels` bytes per texel) — lets tests hand the same texels to the oracle. */
-int de_download_texture(de_ctx* ctx, int slot, uint8_t* out, uint64_t out_bytes);
-int de_texture_info(de_ctx* ctx, int slot, int* width, int* height, int* channels);
 
 /* LUT loading + copy_CIE_LUT_texture / copy_CRF_LUT_texture (renderer.py:96-134,147-167,212-222).
  * cie: CIE.dat as read, f32[(x + y*441)*3 + c]; quantised to f16 inside, like the rgba16f texture.
@@ -145,7 +134,7 @@ int de_reset(de_ctx* ctx);
  * owned by (tile_rank, tile_world) to color_buffer, then current_spp += spp.  The RNG stream of a sample is a
  * function of (seed, absolute pixel index, sample index) only, so images do not depend on tile_world.
  * Ownership: 8x8-pixel tile (tx, ty) belongs to rank (tx + ty) % tile_world.
- * Asynchronous.  Consecutive calls go to internal launch slots in turn (8; 3 for launches with more than 96 MB of per-sample records; env DE_SLOTS / DE_BIG_SLOTS = 1..8) and overlap on
+ * Asynchronous.  Consecutive calls go to internal launch slots in turn (8; 3 for launches with more than 96 MB of per-sample records; de_tuning.launch_slots / big_launch_slots) and overlap on
  * the GPU: k calls of 1 spp — the reference's interactive pattern, earth_viewer.py:241-243 — cost about what one call of
  * k spp costs.  The additions to color_buffer stay in call order (same bits as serial execution). */
 int de_accumulate(de_ctx* ctx, int spp, uint64_t seed, int tile_rank, int tile_world);
@@ -158,6 +147,14 @@ int de_fetch_image(de_ctx* ctx, float* out);
  * Saves the 24.9 MB host-to-host copy and the page faults of a fresh destination: 1920x1080, accumulate(1) + fetch per frame
  * 10.4 -> 9.7 ms (tools/one_spp.py; 9.1 ms of it is the lone launch itself: its longest paths, tools/loop_breakdown.py). */
 int de_fetch_image_view(de_ctx* ctx, const float** host_image);
+/* The window loop PIPELINED (earth_viewer.py:241-251 is accumulate() + fetch_image() per frame; with the synchronous fetch every frame pays its launch's whole
+ * drain — the last long paths of a launch, 7-8 ms — before the host may issue the next).  de_fetch_image_begin enqueues the display transform of the frame as
+ * it stands and its copy into one of TWO pinned buffers on the context stream and returns at once; the host issues the next frame's de_accumulate, whose
+ * render launch runs beside them; de_fetch_image_end waits for the OLDEST fetch begun and not yet ended and hands out its image (valid until the
+ * second-next de_fetch_image_begin).  At most two fetches in flight.  The loop `accumulate; begin; (from the second frame on) end` shows frame k - 1 while
+ * frame k + 1 renders; every image equals the synchronous loop's image of the same frame bit for bit. */
+int de_fetch_image_begin(de_ctx* ctx);
+int de_fetch_image_end(de_ctx* ctx, const float** host_image);
 /* Same transform, result left on the device (pointer valid until the context is destroyed). */
 int de_render_to_image(de_ctx* ctx, const float** device_image);
 /* color_buffer as (W, H, 3) f32 — the raw HDR accumulation (renderer.py:25,330) */
@@ -210,35 +207,11 @@ int de_reduce_progressive(de_ctx* ctx, void* comm, int root);
  * order) it differs by f32 re-association: relative L2 <= 1e-6 (tests).  Perfect balance, no per-tile tail; 12 W H (world - 1) bytes into the root. */
 int de_set_sample_partition(de_ctx* ctx, int rank, int world);
 int de_reduce_ordered(de_ctx* ctx, void* comm, int root, int out_of_place);
-/* Duration of the last de_reduce / de_reduce_progressive on the context stream (HIP events, ms). */
-int de_last_reduce_ms(de_ctx* ctx, float* ms);
 /* Display transform source: a device buffer [H][W][3] f32 to read instead of the accumulation buffer (NULL = back to it) — for
  * hosts that run the out-of-place collective themselves (torch.distributed on a second tensor). */
 int de_set_display_source(de_ctx* ctx, const void* device_ptr);
 int de_synchronize(de_ctx* ctx);
-/* Launches in flight per context (see de_accumulate): n_slots for small launches, n_big for launches with more than 96 MB of
- * per-sample records; 1 = every launch waits for the previous one.  Waits for the launches in flight. */
-int de_set_launch_slots(de_ctx* ctx, int n_slots, int n_big);
-/* Resident waves per CU the render kernel takes (1..20, default 20 = 5 per SIMD, all of the CU's vector registers).  A host that
- * overlaps a collective with the next frame's render leaves room for the collective's kernel: 16 = 4 per SIMD. */
-int de_set_wave_budget(de_ctx* ctx, int waves_per_cu);
 
-/* Duration of the last de_accumulate call measured with HIP events on its launch slot (ms): from the start of its first
- * render launch to the end of its last accumulate_kernel. */
-int de_last_accumulate_ms(de_ctx* ctx, float* ms);
-int de_get_counters(de_ctx* ctx, de_counters* out);
-int de_enable_counters(de_ctx* ctx, int enable);
-/* Which kernels de_accumulate launches.  Same results, bit for bit, whatever the choice.
- *   4 (default)  automatic: a call of at least 4096 paths runs the per-CU stage scheduler (variant 6) in one launch per 2^29 paths; smaller
- *                calls (and counting launches) run the state machine (variant 2), overlapping through the launch slots.  The choice
- *                depends on the call's size only and moves time, never bits.
- *   2            wave-level state machine only (render_kernel_v2.hip)
- *   6            per-CU stage scheduler: ONE launch (+ a small tail launch of the same kernel for big calls, de_tuning.v6_tail_*), two workgroups per CU, the stage queues in LDS, a path stays on its CU (render_kernel_v6.hip)
- * Variants 1 (per-lane loops), 3 (wavefront pipeline through HBM stage queues; with DE_AUTO_V6=0 the launch policy of rounds 3-4) and 5 (stage
- * scheduler over HBM queues) are further statements of path_tracer kept for the cross-check tests: the LEGACY library only
- * (libdigitalearth_hip_legacy.so, include/digital_earth_legacy.h); this library answers DE_ERR_INVALID to them.
- * The ray marcher always runs its own kernel. */
-int de_set_kernel_variant(de_ctx* ctx, int variant);
 
 /* Tuning of the product's kernels as one plain struct — the library reads NO environment variable for any of this (the only ones it
  * reads are DE_RCCL_PATH / DE_RCCL_STRICT, where to find librccl.so); a host that wants experiment overrides reads its own environment
@@ -246,8 +219,11 @@ int de_set_kernel_variant(de_ctx* ctx, int variant);
  * fields, de_set_tuning.  None of the values moves a bit of the image: they move time. */
 typedef struct de_tuning {
     uint32_t struct_bytes;            /* sizeof(de_tuning) of the library that filled it */
-    int32_t kernel_variant;           /* as de_set_kernel_variant: 4 automatic (default), 2 state machine, 6 per-CU stage scheduler */
-    int32_t launch_slots, big_launch_slots;   /* as de_set_launch_slots */
+    int32_t kernel_variant;           /* which kernels de_accumulate launches — same results, bit for bit, whatever the choice.  4 (default) automatic: a call of at least v6_min_paths
+                                         paths runs the per-CU stage scheduler (render_kernel_v6.hip: ONE persistent launch, + a small tail launch of the same kernel for big
+                                         calls), smaller calls and counting launches the wave-level state machine (render_kernel_v2.hip); 2 / 6: that kernel for every call.
+                                         (1, 3, 5: the legacy library only, digital_earth_legacy.h.)  The ray marcher always runs its own kernel */
+    int32_t launch_slots, big_launch_slots;   /* launches in flight per context (see de_accumulate): for small launches / for launches with more than 96 MB of per-sample records; 1 = serial */
     uint64_t v6_min_paths;            /* automatic variant: calls of at least this many paths run render_kernel_v6 (default 4096) */
     int32_t v6_service_area[3];       /* sphere trace / gas / cloud: idle lane-trips since its last service at which a loop stage services; 0 = use v6_service_lanes */
     int32_t v6_service_lanes[3];      /* ... idle lanes at which it does (the rule of round 4) */
@@ -266,44 +242,12 @@ typedef struct de_tuning {
     int32_t v6_stats;                 /* 1: the instrumented instantiation of the kernel (de_debug_v6_stats) */
     int32_t v2_pend, v2_heavy, v2_b, v2_gas, v2_chunk, v2_waves_per_cu, v2_max_spp;   /* render_kernel_v2's scheduler thresholds, work chunk, waves per CU, test split */
     int32_t trace;                    /* 1: print what each call ran to stderr */
+    int32_t v6_cu_withhold;           /* CUs per XCD that the render launches may NOT use (their streams carry a CU mask; the persistent grid shrinks with it): room for the small
+                                         kernels of the context stream — collective, accumulate, display — which otherwise wait for a persistent workgroup to leave.
+                                         0 (default): none.  Changing it waits for the launches in flight */
 } de_tuning;
 int de_get_tuning(de_ctx* ctx, de_tuning* out);
 int de_set_tuning(de_ctx* ctx, const de_tuning* in);
-/* Memory the context may hold for the wavefront pipeline's stage queues and cold records (512 B per path of a batch, per pipe) and the
- * HBM-queue scheduler's pools (kernel variants 3 and 5, and variant 4 under DE_AUTO_V6=0; the default's per-CU scheduler holds 37 MB of cold records + 8 MB of tail pool per
- * launch slot whatever the call and is not affected): a large call is cut into batches that fit (split launches give the same bits; a batch of one sample per
- * pixel that does not fit runs on the state machine).  0 (default) = automatic: what the device has free minus 8 GB, at most 2^27 paths
- * per batch.  Setting it releases what is held.  profiles/memory_budget.md: throughput against the budget.
- * de_get_memory_use: bytes currently held for these buffers. */
-int de_set_memory_budget(de_ctx* ctx, uint64_t bytes);
-int de_get_memory_use(de_ctx* ctx, uint64_t* queue_bytes);
-/* What the last de_accumulate call ran (any pointer may be NULL): *variant = the kernel of its launches (6 = the per-CU stage scheduler, 2 = the
- * state machine, 0 = the ray marcher; in the legacy library also 1, 3 = the wavefront pipeline — with the state machine as finisher when
- * *depths < 25 —, 5 = the HBM-queue scheduler), *pipes = pipelines side by side (legacy; 1 otherwise), *depths = vertex rounds run in the
- * pipeline (legacy; 0 otherwise), *launches = launches the call was cut into.  For a host that reports what it measured. */
-int de_last_call_info(de_ctx* ctx, int* variant, int* pipes, int* depths, int* launches);
-
-/* Debug / test hooks.
- * de_debug_samples: trace sample `sample_index` of every pixel WITHOUT accumulating; per pixel (row-major
- * [H][W]) writes 4 floats: radiance, wavelength, number of RNG draws, number of path vertices.
- * de_debug_math: evaluate a deterministic f32 elementary function on the GPU (fn: 0 exp, 1 log, 2 sin, 3 cos,
- * 4 atan2(a,b), 5 asin, 6 pow(a,b), 7 a/b, 8 sqrt, 9 the short sqrt de_sqrt_nr, 10 the 3-operation a/b for literal divisors, 11 a * RN(1/b) (contract-2 quotient),
- * 12 log of a random draw de_log_unit, 13 the 3-operation reciprocal de_rcp_nr,
- * 14 exp of a non-positive argument de_exp_nonpos), for bit-exact comparison against the oracle. */
-int de_debug_samples(de_ctx* ctx, uint64_t seed, int sample_index, float* out);
-/* Scheduler statistics of render_kernel_v2 gathered while counters are enabled (sums over waves since de_reset):
- * out[0..31] = lane / run counts per section, out[32..43] = shader cycles per section; n <= 48.  Index meaning:
- * tools/sched_stats.py.  Profiling aid only. */
-int de_debug_sched_stats(de_ctx* ctx, uint64_t* out, int n);
-/* The same for the per-CU stage scheduler (kernel variant 6, environment DE_V6_STATS=1); n <= 48: [0..7] records taken per stage
- * (as above), [8..15] wave-time per stage in 10 ns ticks, [16] idle scheduler rounds, [17] stage entries, [18] failed claims of free
- * slots, [19] wave-time in the scheduler, [20] yields of a loop stage, [21] records they handed back, [22] wave-time between the end of the work items and the wave's exit, [32..38] wave-trips of the loop
- * stages / passes of the straight-line stages, [40..46] the busy lanes summed over them.  Profiling aid. */
-/* Phases of the last render_kernel_v6 launch of the last de_accumulate call (the kernel's own 100 MHz clock): ms2[0] = first workgroup start to
- * last wave exit, ms2[1] = the drain, from the first wave that found no work item left to the last wave's exit.  Waits for that launch. */
-int de_last_launch_phases(de_ctx* ctx, float* ms2);
-int de_debug_v6_stats(de_ctx* ctx, uint64_t* out, int n);
-int de_debug_math(de_ctx* ctx, int fn, const float* a, const float* b, float* out, uint64_t n);
 
 const char* de_last_error(void);
 int de_abi_version(void);

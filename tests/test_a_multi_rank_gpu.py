@@ -70,6 +70,49 @@ def test_ranks_on_one_gpu_match_one_rank(tmp_path, world):
     assert j1["config"]["waves_per_cu"] == 24 and "alt" not in j1
 
 
+def test_tile_ownership_is_balanced_at_eight_ranks():
+    # host logic only: the diagonal interleave gives every rank the same number of 8x8 tiles within 1 % at the BASELINE sizes
+    from digital_earth_amd import parallel
+    for (w, h) in ((1920, 1080), (3840, 2160)):
+        t = parallel.tiles_per_rank(w, h, 8)
+        assert t.sum() == (w // 8) * (h // 8) and t.max() / t.min() <= 1.01, (w, h, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("mode", ["tiles", "samples", "gather"])
+def test_eight_ranks_rehearsal_of_the_driver_run(tmp_path, mode):
+    """Exactly what the driver launches for the 8-GPU line (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`), rehearsed with the
+    eight ranks sharing this box's one GPU over gloo, for both partitions and the gather collective: eight ranks seen by the collective, the assembled
+    frame equal to the 1-rank frame (tiles: bit for bit; samples: rank-ordered partial sums, relative L2 <= 1e-6), the tile counts balanced, and a line that
+    parses with `roofline`, `per_rank` and the config's name in it."""
+    solo, multi = str(tmp_path / "solo.npy"), str(tmp_path / "multi.npy")
+    common = [a if a != "3" else "8" for a in COMMON]                     # 8 spp: one sample index per rank under the sample partition
+    p1 = _run([sys.executable, "bench.py", "--gpus", "1", "--dump-hdr", solo] + common)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    extra = {"tiles": ["--split", "tiles"], "samples": ["--split", "samples"], "gather": ["--split", "tiles", "--collective", "gather"]}[mode]
+    port = 29300 + (os.getpid() % 1500) + {"tiles": 0, "samples": 1, "gather": 2}[mode]
+    p2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "bench.py", "--gpus", "8", "--dump-hdr", multi] + extra + common,
+              env_extra={"DE_DIST_BACKEND": "gloo", "DE_NO_LIB_LEG": "1"}, timeout=2000)
+    assert p2.returncode == 0, (p2.stdout[-2000:], p2.stderr[-4000:])
+    j = _json_line(p2.stdout)
+    assert j["n_gpus"] == 8 and j["ranks_seen"] == 8 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["bound"] == "valu_issue" and j["unit"] == "Msamples/s"
+    assert [pr["rank"] for pr in j["per_rank"]] == list(range(8))
+    a, b = np.load(solo), np.load(multi)
+    assert a.max() > 0 and np.isfinite(b).all()
+    if mode == "samples":
+        assert all(pr["samples_per_pixel"] == 1 for pr in j["per_rank"])
+        rel = float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / np.sqrt((a.astype(np.float64) ** 2).sum()))
+        assert rel <= 1e-6 and j["multi_gpu_parity"]["rel_l2"] <= 1e-6, (rel, j["multi_gpu_parity"])
+    else:
+        tiles = [pr["tiles_owned"] for pr in j["per_rank"]]
+        assert sum(tiles) == (256 // 8) * (128 // 8) and max(tiles) / min(tiles) <= 1.01
+        assert j["multi_gpu_parity"]["bit_identical_fraction"] == 1.0
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(1200)
 def test_progressive_frames_on_two_ranks(tmp_path):

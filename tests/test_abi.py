@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "digital_earth.h")).read()
+def declared_symbols(header="digital_earth.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(de_[a-z0-9_]+)\s*\(", text)))
 
@@ -18,18 +18,28 @@ def declared_symbols():
 def test_header_and_binding_agree():
     from digital_earth_amd import _native
     assert declared_symbols() == sorted(_native.SYMBOLS.keys())
+    # the measurement / experiment / test hooks have a header of their own: same library, same discipline
+    assert declared_symbols("digital_earth_debug.h") == sorted(_native.DEBUG_SYMBOLS.keys())
+    assert not set(_native.SYMBOLS) & set(_native.DEBUG_SYMBOLS)
+
+
+def test_the_binders_header_stays_small():
+    """What a binder of the hot path has to read: at most 40 entry points, none of them a debug hook or a knob that only experiments turn."""
+    names = declared_symbols()
+    assert len(names) <= 40, len(names)
+    assert not [n for n in names if n.startswith("de_debug_") or n in ("de_set_wave_budget", "de_set_memory_budget", "de_get_memory_use")]
 
 
 def test_library_exports_every_declared_symbol():
     from digital_earth_amd import _native, build
     build.build()
     lib = _native.load()
-    for name in declared_symbols():
+    for name in declared_symbols() + declared_symbols("digital_earth_debug.h"):
         assert hasattr(lib, name), name
     # the library, the header and the binding carry the same ABI version (a stale .so of another round is refused by load())
     text = open(os.path.join(ROOT, "include", "digital_earth.h")).read()
     header_version = int(re.search(r"#define\s+DE_ABI_VERSION\s+(\d+)", text).group(1))
-    assert lib.de_abi_version() == header_version == _native.ABI_VERSION == 5
+    assert lib.de_abi_version() == header_version == _native.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():

@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: camera math, config round trip, tile partition."""
+import os
 import numpy as np
 
 from digital_earth_amd import parallel
@@ -78,3 +79,52 @@ def test_image_orientation_matches_taichi_imread(tmp_path):
     t = T.load_image_texels(str(p), 1)
     assert t.shape == (4, 6, 1) and (t[0, :, 0] == 10).all() and (t[3, :, 0] == 200).all()
     assert T.load_image_texels(str(p), 3).shape == (4, 6, 3)
+
+
+def _bench_args(argv):
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    old = sys.argv
+    sys.argv = ["bench.py"] + list(argv)
+    try:
+        return bench, bench.parse()
+    finally:
+        sys.argv = old
+
+
+def test_bench_names_the_baseline_configs():
+    """`bench.py --config cfgN` sets the workload from BASELINE.json's wording and the line's metric names it (a cfg4 run used to print
+    the cfg2 metric string).  The table is held to BASELINE.json itself: size, sample count and preset of every config appear in its text."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    texts = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    bench, a = _bench_args([])
+    assert (a.width, a.height, a.spp, a.preset, a.config_name) == (1920, 1080, 64, None, "cfg2")      # the default run IS cfg2
+    for name, c in bench.CONFIGS.items():
+        text = texts[c["index"]]
+        assert "%d×%d" % (c["width"], c["height"]) in text and "%d spp" % c["spp"] in text
+        if c["preset"]:
+            assert c["preset"] in text and os.path.exists(os.path.join(root, "digital_earth_amd", "data", "configs", c["preset"]))
+        assert c["cloud_heavy"] == ("cloud-heavy" in text) and (c["progressive"] > 0) == ("progressive" in text)
+        _, a = _bench_args(["--config", name])
+        assert (a.width, a.height, a.spp, a.preset, bool(a.cloud_heavy), a.progressive, a.config_name) == \
+               (c["width"], c["height"], c["spp"], c["preset"], c["cloud_heavy"], c["progressive"], name)
+        m = bench.metric_name(a.width, a.height, a.spp, a.preset, a.cloud_heavy, a.progressive)
+        assert "%dx%d, %d spp" % (c["width"], c["height"], c["spp"]) in m and (not c["preset"] or c["preset"] in m)
+    # cfg5's film curve is taken by name and the name is one of the shipped curves
+    from digital_earth_amd import luts
+    assert bench.CONFIGS["cfg5"]["crf_name"] in luts.load_crfs()[0]
+    # flags that spell a config are recognised; anything else is not a BASELINE config and says so in its metric
+    _, a = _bench_args(["--preset", "config - florida.txt", "--spp", "256"])
+    assert a.config_name == "cfg3"
+    _, a = _bench_args(["--spp", "16", "--width", "256", "--height", "128"])
+    assert a.config_name is None and "256x128, 16 spp" in bench.metric_name(a.width, a.height, a.spp, a.preset, a.cloud_heavy, a.progressive)
+    # the sparse tiles of the full-sample-count oracle checks: about half a million paths each, never more than a million
+    for name, (rank, world) in bench.SPARSE_CHECK.items():
+        c = bench.CONFIGS[name]
+        paths = (c["width"] // 8) * (c["height"] // 8) / world * 64 * c["spp"]
+        assert 0 <= rank < world and 1e5 < paths < 1.1e6, (name, paths)
