@@ -38,8 +38,8 @@ CONFIGS = {
     "cfg4": dict(index=3, width=3840, height=2160, spp=128, preset="config - sunset hurricane.txt", cloud_heavy=True, progressive=0, crf_name=None),
     "cfg5": dict(index=4, width=1920, height=1080, spp=1024, preset="config - Apollo 11.txt", cloud_heavy=False, progressive=128, crf_name="kaf2001CD.rf"),
 }
-# sparse-tile oracle check of a config at its FULL sample count: every `world`-th 8x8 tile (owner rule of the tile partition), ~0.5 M paths on the host
-SPARSE_CHECK = {"cfg2": (5, 997), "cfg3": (11, 997), "cfg4": (23, 2003), "cfg5": (41, 4051)}
+# sparse-tile oracle check of a config at its FULL sample count: every `stride`-th 8x8 tile in raster order (spread over the whole frame), ~0.5 M paths on the host
+SPARSE_CHECK = {"cfg2": (5, 251), "cfg3": (11, 997), "cfg4": (23, 2003), "cfg5": (41, 4051)}
 
 
 def metric_name(width, height, spp, preset, cloud_heavy, progressive):
@@ -94,6 +94,10 @@ def parse():
                     help="N > 1, tile partition, --reduce torch: sum-reduce of the whole HDR buffer (default) or a gather of each rank's own pixels (1/N of the bytes; SURVEY §8e)")
     ap.add_argument("--serial-frames", action="store_true",
                     help="one launch at a time (launch slots = 1): the collective of frame k never waits behind frame k+1's persistent waves")
+    ap.add_argument("--standin-collective", type=int, default=-1, metavar="COPIES",
+                    help="1-GPU experiment (with --simulate-world N): enqueue a stand-in for the frame's collective where the reduce goes — one streaming kernel over the HDR buffer "
+                         "+ COPIES device-to-device copies of it (7 = the ingress of an 8-rank gather) — and report its queue-to-finish latency (`standin_collective`)")
+    ap.add_argument("--cu-withhold", type=int, default=0, help="CUs per XCD withheld from the render launches' streams (de_tuning.v6_cu_withhold)")
     ap.add_argument("--dump-hdr", default=None, help="rank 0: save the assembled HDR frame of the LAST step as .npy (tests)")
     ap.add_argument("--check-spp", type=int, default=2, help="N > 1: spp of the untimed parity check of the assembled frame against a 1-rank render on rank 0 (0 = skip)")
     args = ap.parse_args()
@@ -181,10 +185,10 @@ def sparse_oracle_check(name, rk, maps, seed):
     """The frame `rk` holds (the config's FULL sample count) against the oracle on every `world`-th 8x8 tile: bit-identical fraction of those pixels."""
     import ctypes
     import numpy as np
-    from digital_earth_amd import luts, parallel
+    from digital_earth_amd import luts
     from oracle import oracle_binding as ob
     W, H = rk.image_res
-    rank, world = SPARSE_CHECK[name]
+    first, stride = SPARSE_CHECK[name]
     g = rk.fetch_hdr()
     o = ob.Oracle(W, H)
     _, crf = luts.load_crfs()
@@ -195,13 +199,14 @@ def sparse_oracle_check(name, rk, maps, seed):
     ctypes.memmove(ctypes.byref(p), ctypes.byref(rk._params), ctypes.sizeof(p))
     o.set_params(p)
     t0 = time.perf_counter()
-    o.accumulate(rk.current_spp, seed, rank, world)
+    o.accumulate_strided(rk.current_spp, seed, first, stride)
     dt = time.perf_counter() - t0
-    mask = parallel.owned_pixel_mask(W, H, rank, world)
+    mask = ob.Oracle.strided_mask(W, H, first, stride)
     c = o.fetch_hdr()
     same = float((c[mask].view(np.uint32) == g[mask].view(np.uint32)).mean())
+    lit = float((c[mask] != 0).any(axis=-1).mean())
     del o
-    return {"bit_identical_vs_oracle_on_sparse_tiles": same, "sparse_tiles": "every %dth 8x8 tile (rank %d of the tile-partition rule), %d pixels x %d spp, oracle %.1f s" % (world, rank, int(mask.sum()), rk.current_spp, dt)}
+    return {"bit_identical_vs_oracle_on_sparse_tiles": same, "sparse_tiles": "every %dth 8x8 tile in raster order (from tile %d), %d pixels x %d spp, %.0f %% of them lit, oracle %.1f s" % (stride, first, int(mask.sum()), rk.current_spp, 100.0 * lit, dt)}
 
 
 def run_other_config(name, r_main, maps, device_index, steps=2):
@@ -349,6 +354,12 @@ def main():
             else:
                 rk.set_tile_partition(0, args.simulate_world)
     r, frame = frames[0].r, frames[0]
+    if args.standin_collective >= 0 and world == 1:
+        for f in frames:
+            f.standin_extra = args.standin_collective
+    if args.cu_withhold > 0:
+        for f in frames:
+            t = f.r.tuning(); t.v6_cu_withhold = args.cu_withhold; f.r.set_tuning(t)
     # Launch settings.  Frames overlap through the library's launch slots (3 for frame-sized launches).  With N > 1 the collective
     # of frame k is then enqueued while frame k+1 renders: the render kernel's persistent waves own every vector register of the
     # CUs (5 per SIMD x 96 VGPRs), so the collective's kernel gets CUs as those waves drain (the frame's tail) — its stream has
@@ -584,6 +595,12 @@ def main():
                  "tracking_steps_per_sample": cnt["tracking_steps"] / max(cnt["samples"], 1),
                  "vertices_per_sample": cnt["vertices"] / max(cnt["samples"], 1)},
     }
+    if args.standin_collective >= 0 and world == 1:
+        out["standin_collective"] = {"extra_copies": args.standin_collective, "queue_to_finish_ms_mean_of_last_16": r.last_reduce_ms(),
+                                     "bytes": (3 + 2 * args.standin_collective) * W * H * 12,
+                                     "note": "one-GPU stand-in for an N-rank run's per-frame collective, enqueued on the context stream where the reduce goes (include/digital_earth_debug.h)"}
+    if args.cu_withhold > 0:
+        out["config"]["cu_withhold_per_xcd"] = args.cu_withhold
     if multi is not None:
         out["multi_gpu_parity"] = multi
     if world > 1:

@@ -15,8 +15,14 @@ DEPS_LEGACY = DEPS + [os.path.join("legacy", f) for f in ("render_kernel_v3.hip"
 # -ffp-contract=off is part of the arithmetic contract (de_math.h): fused operations only where written.
 # -fno-slp-vectorize: the SLP vectoriser packs pairs of scalar f32 operations into v_pk_* instructions; on gfx950 the
 # moves that build the register pairs cost more than the packing saves in this kernel (measured: 358 -> 334 ms per frame).
+# -mllvm -enable-ipra -fno-optimize-sibling-calls (round 6): LLVM's interprocedural register allocation includes the "no callee-saved registers"
+# optimisation for functions with internal linkage that are never tail-called — the stage functions of render_kernel_v6 (static, called from the kernel's
+# scheduler loop only).  Without it every stage entry saved and restored up to 24 callee-saved VGPRs through scratch: 48 scratch operations x 13.9 M stage
+# entries per BASELINE cfg2 frame = 140 GB of fabric traffic (a third of all of it) for values nobody keeps.  -fno-optimize-sibling-calls keeps the `tail`
+# marker off the calls (the optimisation refuses tail-called functions).  Measured, same box: cfg2 104.7 -> 100.9 ms per step, WRITE_SIZE 94.6 -> 49.2 GB,
+# L2 misses 2.61e9 -> 2.03e9 per frame (profiles/experiments/README.md, round 6).  -DDE_V6_UNI_SWITCH: the scheduler's answer dispatched with scalar compares.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",
-         "-shared", "-Wno-unused-value"]
+         "-shared", "-Wno-unused-value", "-mllvm", "-enable-ipra", "-fno-optimize-sibling-calls", "-DDE_V6_UNI_SWITCH"]
 
 
 def needs_build():

@@ -105,7 +105,7 @@ int de_destroy(de_ctx* c) {
     void* ptrs[] = {c->d_cie, c->d_srgb2spec, c->d_o3, c->d_crf, c->d_fc, c->d_nodes, c->d_node_val, c->d_hdr_own, c->d_image, c->d_scratch, c->d_tiles, c->d_counters, c->d_work_counter, c->d_dens_table, c->d_assembled, c->d_gather, c->d_standin};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_stage) hipHostFree(c->h_stage);
-    for (int k = 0; k < 2; ++k) { if (c->h_ring[k]) hipHostFree(c->h_ring[k]); if (c->ev_ring[k]) hipEventDestroy(c->ev_ring[k]); }
+    for (int k = 0; k < DE_FETCH_RING; ++k) { if (c->h_ring[k]) hipHostFree(c->h_ring[k]); if (c->ev_ring[k]) hipEventDestroy(c->ev_ring[k]); }
     if (c->h_issued) hipHostFree(c->h_issued);
 #ifdef DE_LEGACY_VARIANTS
     legacy_destroy(c);
@@ -125,6 +125,7 @@ int de_destroy(de_ctx* c) {
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_r0) hipEventDestroy(c->ev_r0);
     if (c->ev_r1) hipEventDestroy(c->ev_r1);
+    for (auto& pair : c->ev_standin) for (hipEvent_t ev : pair) if (ev) hipEventDestroy(ev);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return DE_OK;
@@ -406,6 +407,10 @@ int de_render_to_image(de_ctx* c, const float** device_image) {
     size_t npx = (size_t)c->W * c->H;
     hipLaunchKernelGGL(display_kernel, dim3((unsigned)((c->W + 31) / 32), (unsigned)((c->H + 31) / 32)), dim3(256), 0, c->stream, d);
     HIP_TRY(hipGetLastError());
+    // what the next accumulate_kernel must wait for ends HERE (the display has read the HDR buffer): recorded now, not lazily at the next de_accumulate, so that
+    // a device-to-host copy of the image enqueued behind the display (de_fetch_image_begin) does not hold the next frame's sums back
+    HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+    c->rec_render = c->gen_render; c->rec_hdr = c->gen_hdr;
     if (device_image) *device_image = c->d_image;
     return DE_OK;
 }
@@ -429,13 +434,13 @@ int de_fetch_image_view(de_ctx* c, const float** host_image) {
     return frame_status(c);
 }
 
-/* The window loop pipelined (include/digital_earth.h).  begin: the display transform of the frame as it stands and its copy into one of two pinned
+/* The window loop pipelined (include/digital_earth.h).  begin: the display transform of the frame as it stands and its copy into one of four pinned
  * buffers are ENQUEUED on the context stream (which waits, on the device, for the launches issued so far); the host returns at once and may issue the
  * next frame's de_accumulate — its render launch runs beside the display and the copy.  end: wait for the oldest fetch begun and hand out its image. */
 int de_fetch_image_begin(de_ctx* c) {
     if (!c) return fail(DE_ERR_INVALID, "null context");
-    if (c->fetch_begun - c->fetch_ended >= 2u) return fail(DE_ERR_STATE, "two fetches are in flight already: de_fetch_image_end first");
-    const int k = (int)(c->fetch_begun & 1u);
+    if (c->fetch_begun - c->fetch_ended >= (unsigned)DE_FETCH_RING) return fail(DE_ERR_STATE, "four fetches are in flight already: de_fetch_image_end first");
+    const int k = (int)(c->fetch_begun % (unsigned)DE_FETCH_RING);
     const size_t bytes = (size_t)c->W * c->H * 3 * sizeof(float);
     HIP_TRY(hipSetDevice(c->device));
     if (!c->h_ring[k]) {
@@ -452,7 +457,7 @@ int de_fetch_image_begin(de_ctx* c) {
 int de_fetch_image_end(de_ctx* c, const float** host_image) {
     if (!c || !host_image) return fail(DE_ERR_INVALID, "null argument");
     if (c->fetch_begun == c->fetch_ended) return fail(DE_ERR_STATE, "no fetch in flight: de_fetch_image_begin first");
-    const int k = (int)(c->fetch_ended & 1u);
+    const int k = (int)(c->fetch_ended % (unsigned)DE_FETCH_RING);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev_ring[k]));
     c->fetch_ended++;

@@ -35,6 +35,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 #define DE_MAX_SLOTS 8
+#define DE_FETCH_RING 4      // de_fetch_image_begin / _end: fetches in flight (a lone one-sample launch takes ~10 ms, its longest path: 2 / 3 / 4 frames in flight run at 5.1 / 4.1 / ~3.5 ms per frame)
 struct LaunchSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;           // recorded after the slot's latest accumulate_kernel
@@ -79,6 +80,9 @@ struct de_ctx {
     int cu_withhold = 0;            // de_tuning.v6_cu_withhold: CUs per XCD the launch slots' streams may NOT use (hipExtStreamCreateWithCUMask), so that small kernels of
                                     // the context stream (collective, accumulate, display) find a free CU while persistent workgroups own the others; 0 = plain streams
     float* d_standin = nullptr;     // second operand of de_debug_standin_reduce (zeros, [H][W][3])
+    hipEvent_t ev_standin[16][2] = {};   // the last 16 stand-in collectives: de_last_reduce_ms answers their MEAN queue-to-finish time (frames in flight: no host wait per frame)
+    unsigned standin_count = 0;
+    bool last_reduce_standin = false;
     hipEvent_t ev_main = nullptr;   // last state of the context stream the slots may have to wait for
     uint64_t gen_render = 1, gen_hdr = 1, rec_render = 0, rec_hdr = 0;   // generations of context-stream work that launches depend on
     int t0_slot = -1, t1_slot = -1;
@@ -101,9 +105,9 @@ struct de_ctx {
     float* d_scratch = nullptr;  // (W, H, 3) / debug [H][W][4]
     float* h_stage = nullptr;     // pinned host staging for fetch_image / fetch_hdr (a pageable destination copies at a fraction of the link rate)
     // de_fetch_image_begin / _end: the window loop pipelined — display + device-to-host copy of frame k run on the context stream while launch k + 1 renders.
-    // Two pinned buffers, two events; fetch_begun / fetch_ended count the calls (begun - ended = fetches in flight, at most 2).
-    float* h_ring[2] = {nullptr, nullptr};
-    hipEvent_t ev_ring[2] = {nullptr, nullptr};
+    // DE_FETCH_RING pinned buffers and events; fetch_begun / fetch_ended count the calls (begun - ended = fetches in flight, at most DE_FETCH_RING).
+    float* h_ring[DE_FETCH_RING] = {};
+    hipEvent_t ev_ring[DE_FETCH_RING] = {};
     unsigned fetch_begun = 0, fetch_ended = 0;
     uint32_t* d_tiles = nullptr;
     int n_tiles = 0, tiles_rank = -1, tiles_world = -1;

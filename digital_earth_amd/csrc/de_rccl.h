@@ -131,7 +131,7 @@ int reduce_impl(de_ctx* c, void* comm, int root, bool progressive) {
     // every rank's buffer is its own tiles plus zeros elsewhere; the root ends with the assembled frame
     RCCL_TRY(g_rccl.Reduce(c->d_hdr, recv, count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, root, use, c->stream));
     HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
-    c->reduce_timing_valid = true;
+    c->reduce_timing_valid = true; c->last_reduce_standin = false;
     if (progressive) {
         touched_hdr(c);                        // the collective READS d_hdr: the next accumulate_kernel is ordered after it
         // only the root receives the assembled frame: elsewhere ncclReduce leaves recvbuff alone, and the display / fetch entry
@@ -207,7 +207,7 @@ int reduce_ordered_impl(de_ctx* c, void* comm, int root, bool out_of_place) {
         RCCL_TRY(g_rccl.Send(c->d_hdr, count, /*ncclFloat32*/ 7, root, use, c->stream));
     }
     HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
-    c->reduce_timing_valid = true;
+    c->reduce_timing_valid = true; c->last_reduce_standin = false;
     touched_hdr(c);                        // the collective reads (root, in place: rewrites) d_hdr: the next accumulate_kernel is ordered after it
     return DE_OK;
 }
@@ -248,15 +248,17 @@ int de_debug_standin_reduce(de_ctx* c, int extra_copies) {
     }
     rc = ordered_root_buffers(c, extra_copies > 0 ? 2 : 1, true);
     if (rc) return rc;
-    if (!c->ev_r0) { HIP_TRY(hipEventCreate(&c->ev_r0)); HIP_TRY(hipEventCreate(&c->ev_r1)); }
-    HIP_TRY(hipEventRecord(c->ev_r0, c->stream));
+    const unsigned e = c->standin_count % 16u;
+    if (!c->ev_standin[e][0]) { HIP_TRY(hipEventCreate(&c->ev_standin[e][0])); HIP_TRY(hipEventCreate(&c->ev_standin[e][1])); }
+    HIP_TRY(hipEventRecord(c->ev_standin[e][0], c->stream));
     for (int k = 0; k < extra_copies; ++k) HIP_TRY(hipMemcpyAsync(c->d_gather, c->d_standin, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     OrderedSumArgs o;
     o.part[0] = c->d_hdr; o.part[1] = c->d_standin; o.out = c->d_assembled; o.n_parts = 2; o.n4 = count / 4; o.n = count;
     hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_r1, c->stream));
-    c->reduce_timing_valid = true;
+    HIP_TRY(hipEventRecord(c->ev_standin[e][1], c->stream));
+    c->standin_count++;
+    c->reduce_timing_valid = true; c->last_reduce_standin = true;
     touched_hdr(c);                        // it READS d_hdr, like the collective: the next accumulate_kernel is ordered after it
     return DE_OK;
 }
@@ -267,6 +269,19 @@ int de_last_reduce_ms(de_ctx* c, float* ms) {
     if (!c || !ms) return fail(DE_ERR_INVALID, "null argument");
     if (!c->reduce_timing_valid) return fail(DE_ERR_STATE, "no de_reduce has been issued");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->last_reduce_standin) {
+        // de_debug_standin_reduce: the mean over the last (up to 16) stand-ins, from the moment the stream reached each to its end
+        const unsigned n = c->standin_count < 16u ? c->standin_count : 16u;
+        double sum = 0.0;
+        for (unsigned k = 0; k < n; ++k) {
+            float t = 0.f;
+            HIP_TRY(hipEventSynchronize(c->ev_standin[k][1]));
+            HIP_TRY(hipEventElapsedTime(&t, c->ev_standin[k][0], c->ev_standin[k][1]));
+            sum += t;
+        }
+        *ms = n ? (float)(sum / n) : 0.f;
+        return DE_OK;
+    }
     HIP_TRY(hipEventSynchronize(c->ev_r1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_r0, c->ev_r1));
     return DE_OK;

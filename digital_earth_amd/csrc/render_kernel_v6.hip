@@ -82,7 +82,7 @@ static_assert(DE_V6_WAVES <= 31, "the lap tag of a ring cell has five bits: one 
 enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G_STAT2 = 8 + 64, G_WORKX = 8 + 64 + 64, G_DRAIN = 8 + 64 + 64 + 8, G_POOL = 8 + 64 + 64 + 8 + 64, G_WORDS = 8 + 64 + 64 + 8 + 64 + 8 };
 // G_POOL + 2 l: entries written to the pool that launch level l exports to; G_POOL + 2 l + 1: entries of that pool handed out to level l + 1 (see "The tail" below)
 // statistics: 0-7 records taken per stage (7 = new paths), 8-15 wave time per stage (100 MHz ticks; 15 = new paths), 16 idle rounds,
-// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
+// 17 stage entries, 18 failed claims, 19 wave time in the scheduler, 20 yields of a loop stage, 21 records handed back by them, 22 wave time between the end of the work items and the wave's exit, 24-30 stage entries per stage (calls of the stage function), 32-38 trips of the loop stages / passes of the straight-line stages, 40-46 busy lanes summed over them
 // region statistics (G_STAT2 + k; STATS builds only): where a wave's time goes and how many lanes the region's vector code runs for.  Per loop stage q
 // (sphere trace, gas, cloud) fourteen words at 14 q: shader-clock ticks and ticks x active lanes of R_STEP (the stage's step(), lanes = busy), R_EPI (finish()
 // + the record's write-back, lanes = finished), R_PUSH (release + ring appends), R_REFILL (claim, take, record load, begin() / restore(), lanes = refilled),
@@ -90,7 +90,7 @@ enum { G_WORK = 0, G_T_START = 1, G_T_EXHAUSTED = 2, G_T_END = 3, G_STAT0 = 8, G
 // straight-line stage q (event, surface, volume finish, surface finish) four words at 42 + 4 (q - 3): ticks and ticks x lanes of the body, ticks of the
 // pass's ring work (claim, take, record load / store, appends), passes.  The same four for new paths (primary sphere trace included) at 58.
 enum { R_STEP = 0, R_EPI, R_PUSH, R_REFILL, R_YIELD, R_HEAD, R_N };
-enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_DRAIN = 22, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
+enum { ST_RECS = 0, ST_CYC = 8, ST_IDLE = 16, ST_ENTRIES = 17, ST_CLAIMFAIL = 18, ST_SCHED = 19, ST_YIELD = 20, ST_YIELDED = 21, ST_DRAIN = 22, ST_ENTRY_Q = 24, ST_TRIPS = 32, ST_LANETRIPS = 40, ST_N = 48 };
 enum { ERR_ENTRY_TIMEOUT = 1, ERR_CELL_BUSY_TIMEOUT = 2, ERR_IDLE_WATCHDOG = 3, ERR_POOL_FULL = 4 };
 // cell values as the 16-bit stores truncate them (the lap's high bits fall off)
 DE_DEV uint32_t cell_empty(uint32_t lap) { return (lap << 11) | DE_V6_SLOT_MASK; }
@@ -715,6 +715,24 @@ struct Wave {
             wf::new_path(a, fc, bs::s_node_val, w, p);
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
+        }
+#if defined(DE_V6_PRIMARY_GAS) && DE_V6_PRIMARY_GAS > 0
+        // EXPERIMENT (VERDICT r5 #1a, its most favourable case): the first DE_V6_PRIMARY_GAS steps of the primary ray's gas segment run HERE, where all 64 lanes
+        // start a gas segment at once, so that a segment that ends within them never becomes a record of the gas stage; what is left goes on as a SUSPENDED
+        // record (the yield path's format: GasStage::suspend / restore, bit for bit).
+        {
+            GasStage gs{uni_ptr(a.nodes), uni_ptr(a.dens_table)};
+            bool g_busy = active && target == Q_GAS, g_fin = false;
+            if (g_busy) gs.begin(p);
+#pragma nounroll
+            for (int k = 0; k < DE_V6_PRIMARY_GAS && __ballot(g_busy) != 0ull; ++k) {
+                if (g_busy && gs.step(p)) { g_busy = false; g_fin = true; }
+            }
+            if (g_fin) target = gs.finish(p);
+            if (g_busy) { gs.suspend(p, cold + slot); p.meta |= 0x80000000u; }
+        }
+#endif
+        if (active) {
             store_rec(rec, slot, p);
             cold[slot].pad0 = wf::asf(p.pid);
         }
@@ -745,7 +763,7 @@ __global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
 
 // ---- the stage functions: NOT inlined into the kernel — one register allocation per stage (see "Geometry").  A stage function builds
 // its view of the wave from LDS, runs the stage until its ring is dry (or it hands its records back) and returns to the scheduler.
-#define DE_V6_STAGE template <bool CLAMP, bool STATS> __device__ __attribute__((noinline)) void
+#define DE_V6_STAGE template <bool CLAMP, bool STATS> static __device__ __attribute__((noinline)) void
 DE_V6_STAGE v6_stage_st(bool primary_left) {
     using namespace bs;
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
@@ -807,7 +825,7 @@ DE_V6_STAGE v6_stage_export(bool primary_left) {
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
     W.run_export(Targets<Q_ST, Q_GAS, Q_CLOUD, Q_EVENT, Q_SURF, Q_SCFIN, Q_SURFFIN>{});
 }
-template <bool CLAMP, bool STATS> __device__ __attribute__((noinline)) bool v6_stage_import() {      // false: the pool is exhausted
+template <bool CLAMP, bool STATS> static __device__ __attribute__((noinline)) bool v6_stage_import() {      // false: the pool is exhausted
     using namespace bs;
     Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
     W.run_import();
@@ -843,7 +861,11 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
     W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (;;) {
+#ifdef DE_V6_UNI_SWITCH
+        const int s = __builtin_amdgcn_readfirstlane(W.schedule());      // wave-uniform by construction: said so, the dispatch below is scalar compares instead of an exec-masked branch tree
+#else
         const int s = W.schedule();
+#endif
         W.template mark<-1>();
         if (s == Q_EXIT) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -851,6 +873,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
             if (STATS && W.t_drain) W.stat(ST_DRAIN, now - W.t_drain);
             break;
         }
+        if (STATS && s < NQ) W.stat(ST_ENTRY_Q + s, 1);
         switch (s) {
         case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
         case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;

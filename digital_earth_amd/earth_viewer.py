@@ -221,8 +221,8 @@ class EarthViewer:
              exposure, camera response and gamma do not (display-only)                            (:268-305)
           4. the scalars are written to the renderer, then the reset happens                       (:308-317)
         Returns the displayed image of step 2 (copy=False: a read-only view that the next frame() overwrites — what a canvas needs).
-        pipelined=True: the display and the host copy of this frame are only enqueued (Renderer.fetch_image(lag=1)) and the image RETURNED is the
-        previous iteration's (None in the first): the next iteration's accumulate() renders while this frame is shown — the same images, one
+        pipelined=True (or 2: two frames of lag): the display and the host copy of this frame are only enqueued (Renderer.fetch_image(lag=...)) and the
+        image RETURNED is the previous iteration's (None in the first): the next iteration's accumulate() renders while this frame is shown — the same images, one
         iteration later, at a fraction of the frame time; finish() returns the last one."""
         r = self.renderer
         should_reset = False
@@ -232,7 +232,7 @@ class EarthViewer:
             r.set_up(*self.camera._up)
             should_reset = True
         r.accumulate(int(spp))                  # == accumulate() x spp, bit for bit
-        self._image = r.fetch_image(copy=copy, lag=1 if pipelined else 0)
+        self._image = r.fetch_image(copy=copy, lag=int(pipelined))
         if self._sliders is None:               # current_* of earth_viewer.py:191-199, read once when the loop starts
             self._sliders = {"sun_angle": r.sun_angle[None], "sun_path_rot": r.sun_path_rot[None], "fov": r.fov[None],
                              "aspect_scale": r.aspect_scale[None], "exposure": r.exposure[None],

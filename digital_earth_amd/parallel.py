@@ -176,6 +176,7 @@ class DistributedFrame:
         self.assembled = None                       # root's frame of the out-of-place (progressive) reduce
         self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self._timed = False
+        self.standin_extra = None                   # one-GPU experiments: an int makes _reduce enqueue the stand-in collective (Renderer.debug_standin_reduce) when world == 1
         renderer.bind_hdr(self.hdr.data_ptr(), self.hdr.numel())
         renderer.set_stream(self.stream.cuda_stream)
         renderer._bound = (self.hdr, self.stream)
@@ -191,6 +192,8 @@ class DistributedFrame:
         # after the launches — they run on the context's launch slots, not on this stream
         self.r.flush()
         self._ev[0].record(self.stream)
+        if self.world == 1 and self.standin_extra is not None:
+            self.r.debug_standin_reduce(self.standin_extra)      # where the collective of an N-rank run goes: after the launches, before the display
         if self.split == "samples":
             reduce_hdr_ordered(self.hdr, dst=0, out=out)
         elif self.collective == "gather":

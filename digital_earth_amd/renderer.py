@@ -400,18 +400,19 @@ class Renderer:
         view of the library's pinned staging buffer, valid until the next fetch_* call on this renderer (what a window loop needs: it
         hands the image to the canvas before it renders again) — no 24.9 MB host copy, no fresh pages.
 
-        lag=1: the window loop PIPELINED (de_fetch_image_begin / _end).  The display transform and the device-to-host copy of the frame as it
-        stands are only ENQUEUED; the call returns the image of the PREVIOUS lag=1 call (None the first time), so the caller's next
-        accumulate() renders while this frame is displayed and copied.  Every image equals what the synchronous loop returns for the same
-        frame, bit for bit, one call later; fetch_pending() hands out the last one."""
+        lag=1, 2 or 3: the window loop PIPELINED (de_fetch_image_begin / _end).  The display transform and the device-to-host copy of the frame as it
+        stands are only ENQUEUED; the call returns the image of the lag-th PREVIOUS call (None until there is one), so the caller's next
+        accumulate() renders while this frame is displayed and copied.  A lone one-sample launch takes ~10 ms (its longest path), so lag=1 runs
+        at ~5.1 ms per 1080p frame, lag=2 at ~4.1 ms, lag=3 at ~3.5 ms (the floor, launches back to back without any fetch, is 2.9 ms).  Every image equals what the synchronous loop returns for the same frame, bit for bit,
+        `lag` calls later; fetch_pending() hands out the rest.  A view (copy=False) stays valid until the next fetch_image call."""
         if not self._textures_copied:
             self.copy_textures()
-        if lag not in (0, 1):
-            raise ValueError("lag must be 0 or 1")
+        if lag not in (0, 1, 2, 3):
+            raise ValueError("lag must be 0 ... 3")
         if lag:
             check(self._lib.de_fetch_image_begin(self._h))
             self._fetches = getattr(self, "_fetches", 0) + 1
-            if self._fetches < 2:
+            if self._fetches <= lag:
                 return None
             return self._fetch_end(copy)
         if getattr(self, "_fetches", 0):
@@ -431,12 +432,15 @@ class Renderer:
         view = self._staging_view(ptr)
         return np.array(view) if copy else view
 
-    def fetch_pending(self, copy=True):
-        """End the pipelined window loop: wait for the fetches still in flight and return the newest image (None when there is none)."""
-        img = None
+    def fetch_pending(self, copy=True, all_images=False):
+        """End the pipelined window loop: wait for the fetches still in flight and return the newest image (None when there is none);
+        all_images=True: the list of all of them, oldest first (copies)."""
+        imgs = []
         while getattr(self, "_fetches", 0) > 0:
-            img = self._fetch_end(copy)
-        return img
+            imgs.append(self._fetch_end(copy or all_images))
+        if all_images:
+            return imgs
+        return imgs[-1] if imgs else None
 
     def fetch_hdr(self):
         out = np.empty((self.image_res[0], self.image_res[1], 3), dtype=np.float32)

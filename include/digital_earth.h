@@ -148,11 +148,12 @@ int de_fetch_image(de_ctx* ctx, float* out);
  * 10.4 -> 9.7 ms (tools/one_spp.py; 9.1 ms of it is the lone launch itself: its longest paths, tools/loop_breakdown.py). */
 int de_fetch_image_view(de_ctx* ctx, const float** host_image);
 /* The window loop PIPELINED (earth_viewer.py:241-251 is accumulate() + fetch_image() per frame; with the synchronous fetch every frame pays its launch's whole
- * drain — the last long paths of a launch, 7-8 ms — before the host may issue the next).  de_fetch_image_begin enqueues the display transform of the frame as
- * it stands and its copy into one of TWO pinned buffers on the context stream and returns at once; the host issues the next frame's de_accumulate, whose
- * render launch runs beside them; de_fetch_image_end waits for the OLDEST fetch begun and not yet ended and hands out its image (valid until the
- * second-next de_fetch_image_begin).  At most two fetches in flight.  The loop `accumulate; begin; (from the second frame on) end` shows frame k - 1 while
- * frame k + 1 renders; every image equals the synchronous loop's image of the same frame bit for bit. */
+ * latency — ~10 ms at 1920x1080 for 1.7 ms of work: the launch's longest path is a serial chain — before the host may issue the next).  de_fetch_image_begin
+ * enqueues the display transform of the frame as it stands and its copy into one of FOUR pinned buffers on the context stream and returns at once; the host
+ * issues the next frame's de_accumulate, whose render launch runs beside them; de_fetch_image_end waits for the OLDEST fetch begun and not yet ended and hands
+ * out its image (its buffer is filled again by the fourth de_fetch_image_begin after the one that filled it).  At most four fetches in flight.  The loop `accumulate; begin; (once
+ * L fetches are in flight) end` shows frame k - L while frame k + 1 renders, L = 1, 2 or 3; every image equals the synchronous loop's image of the same frame
+ * bit for bit. */
 int de_fetch_image_begin(de_ctx* ctx);
 int de_fetch_image_end(de_ctx* ctx, const float** host_image);
 /* Same transform, result left on the device (pointer valid until the context is destroyed). */

@@ -63,6 +63,7 @@ def lib():
         L.deo_get_params.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeParams)]
         L.deo_reset.argtypes = [ctypes.c_void_p]
         L.deo_accumulate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+        L.deo_accumulate_strided.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
         L.deo_debug_samples.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
         L.deo_fetch_image.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.deo_fetch_hdr.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -150,6 +151,17 @@ class Oracle:
 
     def accumulate(self, spp=1, seed=0, tile_rank=0, tile_world=1):
         _check(lib().deo_accumulate(self._h, spp, seed, tile_rank, tile_world))
+
+    def accumulate_strided(self, spp, seed, first, stride):
+        """The checker's sparse subset: only the 8x8 tiles whose raster index = first (mod stride) — spread over the whole frame."""
+        _check(lib().deo_accumulate_strided(self._h, spp, seed, first, stride))
+
+    @staticmethod
+    def strided_mask(width, height, first, stride):
+        """(W, H) boolean mask of the pixels accumulate_strided renders."""
+        tx = np.arange(width) // 8
+        ty = np.arange(height) // 8
+        return ((ty[None, :] * (width // 8) + tx[:, None]) % stride) == first
 
     def set_sample_partition(self, rank, world):
         """Of the frame's sample indices this oracle renders those = rank (mod world); accumulate(spp) still advances the index by spp."""

@@ -59,3 +59,15 @@ def test_render_kernel_v6_budget_and_hot_loops(tmp_path):
     spec.loader.exec_module(mod)
     for stage, r in mod.hot_loops(asm).items():
         assert r["mid_scratch"] == 0, (stage, r)
+    # Round 6: the stage functions have internal linkage and the build carries -mllvm -enable-ipra -fno-optimize-sibling-calls, so LLVM's no-CSR optimisation
+    # applies — no stage function saves callee-saved VGPRs through scratch any more (it was 13-24 stores + as many loads per entry, 13.9 M entries per cfg2 frame:
+    # a third of the kernel's fabric traffic).  A flag or a linkage that gets lost shows here.
+    text = open(asm).read()
+    seen = 0
+    for f in re.split(r"\n(?=_Z[\w]+:\s+; @)", text):
+        m = re.match(r"(_ZL\d+v6_stage_[a-z]+ILb[01]ELb0EE\w+):", f)      # the shipped instantiations (the statistics build spills a few of its own)
+        if not m:
+            continue
+        seen += 1
+        assert len(re.findall(r"scratch_store", f)) <= 4 and len(re.findall(r"scratch_load", f)) <= 4, (m.group(1), len(re.findall(r"scratch_", f)))
+    assert seen >= 18      # nine stage functions x at least the two product instantiations (REPEAT / CLAMP)

@@ -32,8 +32,8 @@ def _parts(n_parts, shape, seed=5):
 def test_ordered_sum_kernel_with_several_parts(Renderer, n_parts, root, out_of_place):
     """de_reduce_ordered's root half — the gather buffer's per-rank offsets, the root's part read IN PLACE, ordered_sum_kernel with
     n_parts > 1 — had never executed: RCCL refuses two ranks on one device.  de_debug_ordered_sum feeds the same launch from the host.  Result =
-    ((p0 + p1) + p2) + ... in f32, bit for bit, wherever the root sits; an odd pixel count exercises the scalar tail of the float4 loop."""
-    W, H = 80, 24                                  # 80 * 24 * 3 = 5760 floats: a multiple of 4 ...
+    ((p0 + p1) + p2) + ... in f32, bit for bit, wherever the root sits."""
+    W, H = 80, 24
     r = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(256, 128))
     parts = _parts(n_parts, (W, H, 3))
     got = r.debug_ordered_sum(parts, root=root, out_of_place=out_of_place)
@@ -45,7 +45,7 @@ def test_ordered_sum_kernel_with_several_parts(Renderer, n_parts, root, out_of_p
     other = parts[-1].copy()
     for p in parts[-2::-1]:
         other = other + p
-    assert (other.view(np.uint32) != want.view(np.uint32)).any()
+    assert n_parts == 2 or (other.view(np.uint32) != want.view(np.uint32)).any()
     # in place: the accumulation buffer now holds the assembled frame; out of place: the display source does, the accumulation buffer keeps the root's part
     assert (r.fetch_hdr().view(np.uint32) == want.view(np.uint32)).all()
     if out_of_place:
@@ -74,9 +74,10 @@ def test_ordered_sum_of_rendered_sample_partitions_equals_the_host_assembly(Rend
 
 
 @pytest.mark.timeout(600)
-def test_pipelined_window_loop_equals_the_synchronous_one_shifted_by_a_frame(Renderer):
-    """accumulate(1) + fetch_image(lag=1) per frame returns frame k - 1 while frame k + 1 renders; the sequence of images equals the
-    synchronous loop's, one call later, bit for bit — through a reset in the middle (a moved camera) too."""
+@pytest.mark.parametrize("lag", [1, 2, 3])
+def test_pipelined_window_loop_equals_the_synchronous_one_shifted_by_a_frame(Renderer, lag):
+    """accumulate(1) + fetch_image(lag=L) per frame returns frame k - L while frame k + 1 renders; the sequence of images equals the
+    synchronous loop's, L calls later, bit for bit — through a reset in the middle (a moved camera) too."""
     W, H, N = 256, 128, 7
     a = Renderer((W, H), (0, 1, 0), texture_source="synthetic", texture_size=(2048, 1024), seed=3)
     a.set_fov(0.42); a.copy_textures()
@@ -93,18 +94,19 @@ def test_pipelined_window_loop_equals_the_synchronous_one_shifted_by_a_frame(Ren
         if k == 4:
             b.set_fov(0.3); b.reset_framebuffer()
         b.accumulate(1)
-        lagged.append(b.fetch_image(lag=1))
-    assert lagged[0] is None
+        lagged.append(b.fetch_image(lag=lag))
+    assert all(x is None for x in lagged[:lag]) and all(x is not None for x in lagged[lag:])
     with pytest.raises(RuntimeError):
         b.fetch_image()                       # a synchronous fetch while lagged ones are in flight would hand out frames out of order
-    last = b.fetch_pending()
-    assert b.fetch_pending() is None
-    got = lagged[1:] + [last]
+    rest = b.fetch_pending(all_images=True)
+    assert len(rest) == lag and b.fetch_pending() is None
+    got = lagged[lag:] + rest
     for k in range(N):
         assert got[k].shape == (W, H, 3) and (got[k].view(np.uint32) == sync[k].view(np.uint32)).all(), k
     # zero-copy views of the pipelined loop: valid until the next fetch, and close() refuses while one is referenced
-    b.accumulate(1); assert b.fetch_image(lag=1, copy=False) is None
-    b.accumulate(1); v = b.fetch_image(lag=1, copy=False)
+    for _ in range(lag):
+        b.accumulate(1); assert b.fetch_image(lag=lag, copy=False) is None
+    b.accumulate(1); v = b.fetch_image(lag=lag, copy=False)
     a.accumulate(1); want = a.fetch_image()
     assert not v.flags.writeable and (np.asarray(v).view(np.uint32) == want.view(np.uint32)).all()
     with pytest.raises(RuntimeError):
@@ -114,14 +116,14 @@ def test_pipelined_window_loop_equals_the_synchronous_one_shifted_by_a_frame(Ren
 
 
 @pytest.mark.timeout(600)
-def test_three_fetches_in_flight_are_refused(Renderer):
+def test_five_fetches_in_flight_are_refused(Renderer):
     from digital_earth_amd import _native
     r = _small(Renderer)
     r.accumulate(1)
-    _native.check(r._lib.de_fetch_image_begin(r._h))
-    _native.check(r._lib.de_fetch_image_begin(r._h))
-    assert r._lib.de_fetch_image_begin(r._h) == -4            # DE_ERR_STATE
-    r._fetches = 2
+    for _ in range(4):
+        _native.check(r._lib.de_fetch_image_begin(r._h))
+    assert r._lib.de_fetch_image_begin(r._h) == -4            # DE_ERR_STATE: four fetches in flight is the ring's size
+    r._fetches = 4
     assert r.fetch_pending() is not None
     import ctypes
     ptr = ctypes.POINTER(ctypes.c_float)()

@@ -124,7 +124,12 @@ def test_bench_names_the_baseline_configs():
     _, a = _bench_args(["--spp", "16", "--width", "256", "--height", "128"])
     assert a.config_name is None and "256x128, 16 spp" in bench.metric_name(a.width, a.height, a.spp, a.preset, a.cloud_heavy, a.progressive)
     # the sparse tiles of the full-sample-count oracle checks: about half a million paths each, never more than a million
-    for name, (rank, world) in bench.SPARSE_CHECK.items():
+    from oracle import oracle_binding as ob
+    for name, (first, stride) in bench.SPARSE_CHECK.items():
         c = bench.CONFIGS[name]
-        paths = (c["width"] // 8) * (c["height"] // 8) / world * 64 * c["spp"]
-        assert 0 <= rank < world and 1e5 < paths < 1.1e6, (name, paths)
+        mask = ob.Oracle.strided_mask(c["width"], c["height"], first, stride)
+        paths = int(mask.sum()) * c["spp"]
+        assert 0 <= first < stride and 2e5 < paths < 1.1e6, (name, paths)
+        # spread over the frame: tiles in every quarter of the image
+        w2, h2 = c["width"] // 2, c["height"] // 2
+        assert all(q.any() for q in (mask[:w2, :h2], mask[w2:, :h2], mask[:w2, h2:], mask[w2:, h2:])), name

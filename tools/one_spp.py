@@ -53,6 +53,22 @@ for _ in range(30):
     r.accumulate(1); img = r.fetch_image(copy=False)
 t1 = time.perf_counter()
 print("the same with fetch_image(copy=False) (a view of the pinned staging buffer): %.2f ms" % ((t1 - t0) * 1e3 / 30))
+# the same loop PIPELINED (round 6: de_fetch_image_begin / _end): the display + host copy of frame k are enqueued, frame k + 1 is issued at once and the
+# image handed to the canvas is frame k - 1's — with and without CUs withheld from the render streams for the display kernel and the copy
+def pipelined(n, lag):
+    r.fetch_pending()
+    for _ in range(6):
+        r.accumulate(1); r.fetch_image(copy=False, lag=lag)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r.accumulate(1); img = r.fetch_image(copy=False, lag=lag)
+    dt = (time.perf_counter() - t0) * 1e3 / n
+    r.fetch_pending(copy=False)
+    return dt
+
+
+for lag in (1, 2, 3):
+    print("pipelined loop, accumulate(1) + fetch_image(copy=False, lag=%d) per frame (the image shown is %d frame%s old): %.2f ms" % (lag, lag, "" if lag == 1 else "s", min(pipelined(90, lag) for _ in range(3))))
 if "--check" in sys.argv:
     r.reset_framebuffer(); r.accumulate(16); a = r.fetch_hdr()
     r.reset_framebuffer()

@@ -6,8 +6,9 @@ resource line, which only counts the callee-saved registers at the stage functio
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGES = {"sphere trace": "_Z11v6_stage_stILb0ELb0EEvb", "gas": "_Z12v6_stage_gasILb0ELb0EEvb", "cloud": "_Z14v6_stage_cloudILb0ELb0EEvb"}
-FLAT = {"event": "_Z14v6_stage_eventILb0ELb0EEvb", "surface": "_Z13v6_stage_surfILb0ELb0EEvb", "vol finish": "_Z14v6_stage_scfinILb0ELb0EEvb", "surf finish": "_Z16v6_stage_surffinILb0ELb0EEvb"}
+# (internal linkage since round 6 — the no-CSR optimisation of -mllvm -enable-ipra needs it —: _ZL...)
+STAGES = {"sphere trace": "_ZL11v6_stage_stILb0ELb0EEvb", "gas": "_ZL12v6_stage_gasILb0ELb0EEvb", "cloud": "_ZL14v6_stage_cloudILb0ELb0EEvb"}
+FLAT = {"event": "_ZL14v6_stage_eventILb0ELb0EEvb", "surface": "_ZL13v6_stage_surfILb0ELb0EEvb", "vol finish": "_ZL14v6_stage_scfinILb0ELb0EEvb", "surf finish": "_ZL16v6_stage_surffinILb0ELb0EEvb"}
 
 
 def mid_scratch(lines):
