@@ -219,7 +219,7 @@ hipError_t launch_v6(de_ctx* c, const RenderArgs& a, hipStream_t stream, int idx
     if (e != hipSuccess) return e;
     A.status = d_status;
     A.n_items = (uint32_t)((size_t)a.n_tiles * 64u * (size_t)a.spp_count);
-    A.idle_limit = 1u << 24;      // ~7 s of idling
+    A.idle_limit = 1u << 22;      // ~10 s of idling (an idle round ends in a sleep of up to 2.7 us: render_kernel_v6.hip schedule())
     for (int k = 0; k < 3; ++k) { A.svc[k] = (uint32_t)c->v6_svc[k]; A.svc_area[k] = (uint32_t)c->v6_svc_area[k]; }
     A.yield_max = (uint32_t)c->v6_yield; A.elsewhere_min = (uint32_t)c->v6_elsewhere; A.retry = (uint32_t)c->v6_retry; A.enter_min = (uint32_t)c->v6_enter_min; A.flat_min = (uint32_t)c->v6_flat_min; A.flat_again = (uint32_t)(c->v6_flat_again > 0 ? c->v6_flat_again : 1);
     A.bands = c->v6_bands == 8 ? 8u : 1u;

@@ -161,12 +161,18 @@ static_assert(sizeof(Cfg) % 4 == 0 && sizeof(Cfg) <= 160, "Cfg is copied dword b
 __shared__ uint4 s_rec[3u * DE_V6_P];                // the record slots: three 16-byte parts, part-major ...
 __shared__ uint2 s_rec2[DE_V6_P];                    // ... and one of 8 bytes
 __shared__ uint16_t s_rings[(NQ + 1) * DE_V6_CAP];   // NR rings of slot numbers
-__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16, drain statistics at 17, "exporting" at 18, waves that may still start paths at 19, the export decision at 20
+__shared__ uint32_t s_cw[32];                        // head[NR] at 0, tail[NR] at 8, abort at 16, drain statistics at 17, "exporting" at 18, image bands left behind (>= the launch's band count: nothing left to start) at 19, the export decision at 20
 __shared__ float s_node_val[64];
 __shared__ unsigned long long s_stats[64];
 __shared__ uint32_t s_cfg[40];
 
+// (the lane's index from the execution-mask counters, not from threadIdx: a stage function that never asks for the work-item id does not receive it — one VGPR
+// more for its allocator, and the scheduler loop has no packed id to keep alive, i.e. to reload from scratch, for every stage call)
+#ifdef DE_V6_LANE_TID
 DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+#else
+DE_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#endif
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // What a stage reads of the launch (map descriptors, table pointers, frame constants) arrives through a pointer the optimiser cannot see through
 // — as flat loads into VECTOR registers, although every lane gets the same value.  Broadcast to scalar registers: a map's seven dwords in
@@ -230,9 +236,8 @@ struct Wave {
     uint32_t* cw;               // LDS: head[NR] at 0, tail[NR] at 8, abort at 16
     wf::Cold* cold;             // the workgroup's cold records
     unsigned long long* s_st;   // LDS: statistics
-    uint32_t n_work, w_lo, w_hi, w_tries;
-    bool primary_left, aborted;
-    unsigned long long t_mark, t_drain;
+    bool primary_left, aborted;      // primary_left: the workgroup's band progress (cw[19]) as this wave last read it — see starters()
+    unsigned long long t_mark;
     unsigned long long r_t[R_N], r_l[R_N], r_last, r_cnt[2];      // region statistics of the running stage (STATS builds only)
 
     DE_DEV void regions_begin() {
@@ -265,13 +270,17 @@ struct Wave {
     }
 
     // a stage function's view of the wave: the configuration from LDS (scalar registers after the broadcast), the wave's own flag
-    DE_DEV static Wave enter(bool primary_left) {
+    // (Round 6: a wave carries NOTHING from one stage to the next.  What used to travel — the rest of a 256-item work claim, the wave's own "nothing left to
+    // start" flag — is gone: work items are claimed 64 at a time AFTER the free slots, and how far the workgroup has come through the image bands is one word of
+    // LDS, cw[19].  With the stage functions' callee-saved registers gone (build.py: -enable-ipra) every value the kernel kept live across a stage call cost a
+    // scratch store and a load per stage entry; now the scheduler loop re-reads the few configuration words it needs from LDS and keeps none.)
+    DE_DEV static Wave enter() {
         Wave W;
         uint32_t* dst = reinterpret_cast<uint32_t*>(&W.A);
 #pragma unroll
         for (uint32_t k = 0; k < sizeof(Cfg) / 4u; ++k) dst[k] = uni(s_cfg[k]);
         W.rec = s_rec; W.rings = s_rings; W.cw = s_cw; W.cold = W.A.cold; W.s_st = s_stats;
-        W.n_work = W.A.n_items; W.w_lo = W.w_hi = 0u; W.w_tries = 0u; W.primary_left = primary_left; W.aborted = false; W.t_mark = 0ull; W.t_drain = 0ull;
+        W.primary_left = true; W.aborted = false; W.t_mark = 0ull;
         return W;
     }
 
@@ -296,6 +305,10 @@ struct Wave {
         if (!aborted && uni(ld_wg(cw + 16)) != 0u) aborted = true;
         return aborted;
     }
+
+    // Can this workgroup still start paths?  cw[19] counts the image bands it has found exhausted (run_primary; a tail launch's import stores all ones when
+    // the pool is): below the launch's band count, yes.  Monotonic, so a "no" is final — from then on the workgroup's population only falls.
+    DE_DEV bool starters() { primary_left = uni(ld_wg(cw + 19)) < A.bands; return primary_left; }
 
     // claim between kmin and kmax entries of ring q: a compare-and-swap on its head, never past its tail
     DE_DEV uint32_t claim(uint32_t q, uint32_t kmin, uint32_t kmax, uint32_t* first) {
@@ -385,10 +398,17 @@ struct Wave {
     DE_DEV int schedule() {
         uint32_t idle = 0;
         for (;;) {
-            if (abort_seen()) return Q_EXIT;
-            int ready = 0;
+            // ONE batch of LDS reads per round: the control words 16 .. 23 (abort, drain, exporting, band progress, the export decision) in lanes 0 .. 7 and the
+            // rings' depths, issued back to back and waited for once (the abort word used to be a round trip of its own before the others were even issued).
+            // The band word is READ before the ring counters — LDS executes a wave's operations in order —: once it says "nothing left to start" the free ring
+            // read after it bounds the population for good.
             const uint32_t l = (uint32_t)lane_id();
+            const uint32_t misc = ld_wg(cw + 16 + (l & 7u));
+            int ready = 0;
             if (l < (uint32_t)NR) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
+            if (!aborted && __builtin_amdgcn_readlane((int)misc, 0) != 0) aborted = true;
+            if (aborted) return Q_EXIT;      // the workgroup's own word: the workgroups share nothing but the work counters, the others finish their paths
+            primary_left = (uint32_t)__builtin_amdgcn_readlane((int)misc, 3) < A.bands;
             int best_q = -1, best = 0, low_q = -1, low = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -405,22 +425,16 @@ struct Wave {
             if (STATS && !primary_left) drain_sample((uint32_t)((int)DE_V6_P - free_slots));
             if (A.export_at != 0u && !primary_left) {
                 // the tail: nothing left to start and few paths alive — from here on this workgroup only exports (see "The tail")
-                uint32_t live = DE_V6_P - (uint32_t)free_slots;
-                // (only once EVERY wave of the workgroup knows that nothing is left to start — a wave may hold the rest of a 256-item claim while it works in a
-                // stage: from then on the population can only fall, so a workgroup exports at most export_at records and the pool cannot overflow)
-                uint32_t two = 0;
-                if (lane_id() < 2) two = ld_wg(cw + 18 + lane_id());
-                bool exporting = __builtin_amdgcn_readlane((int)two, 0) != 0;
-                const bool starters = __builtin_amdgcn_readlane((int)two, 1) != 0;
-                // (`ready` was read BEFORE the starters word: a wave that started 64 more paths and gave up its starter's role between the two reads would leave
-                // `live` too small and the workgroup could export more than export_at records — the bound the pool is sized by.  Once no starter is left the
-                // population only falls: the free ring read again AFTER that observation is an upper bound for good.  ADVICE r5)
-                if (!exporting && !starters) live = DE_V6_P - uni(ld_wg(tail(Q_FREE)) - ld_wg(head(Q_FREE)));
-                if (!exporting && !starters && live != 0u && live <= A.export_at) {
+                const uint32_t live = DE_V6_P - (uint32_t)free_slots;
+                // (nothing is left to start for the WHOLE workgroup — cw[19], read before the rings above: from then on the population can only fall — a wave that
+                // is still inside run_primary holds its 64 slots out of the free ring, so they count as alive — and a workgroup exports at most export_at records:
+                // the pool cannot overflow)
+                bool exporting = __builtin_amdgcn_readlane((int)misc, 2) != 0;
+                if (!exporting && live != 0u && live <= A.export_at) {
                     // Export only if another launch of this context is queued behind this one: the slots this workgroup frees are then taken at once, which is
                     // what the chain is for; a launch with nothing behind it (a frame rendered alone, the last call before a fetch) would only end later for it —
                     // the tail launch cannot start before the last workgroup here has exported.  Decided once per workgroup (one read of host memory).
-                    uint32_t dec = uni(ld_wg(cw + 20));      // 0: not decided, 1: export, 2: finish in place
+                    uint32_t dec = (uint32_t)__builtin_amdgcn_readlane((int)misc, 4);      // 0: not decided, 1: export, 2: finish in place
                     if (dec == 0u) {
                         if (lane_id() == 0) {
                             dec = (A.seq == 0xffffffffu || (int)(__hip_atomic_load(A.issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) >= 0) ? 1u : 2u;
@@ -447,7 +461,17 @@ struct Wave {
             if (!primary_left && free_slots == (int)DE_V6_P) return Q_EXIT;      // every slot is home and nothing is left to start
             stat(ST_IDLE, 1);
             if (++idle > A.idle_limit) { raise(ERR_IDLE_WATCHDOG); return Q_EXIT; }
-            if (idle < 16u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+            // An idle wave backs off: a scheduler round is ~100 instructions, and in a launch's drain — most of a one-sample launch — eleven of a workgroup's twelve
+            // waves are idle: at one round per ~0.5 us they took a third of the instructions such a launch executes, from the working waves of the launches that
+            // overlap with it.  With twelve waves waking at different times a record still waits only a fraction of one sleep.
+#ifndef DE_V6_IDLE_BACKOFF
+#define DE_V6_IDLE_BACKOFF 1
+#endif
+            if (!DE_V6_IDLE_BACKOFF) { if (idle < 16u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16); }
+            else if (idle < 8u) __builtin_amdgcn_s_sleep(2);
+            else if (idle < 24u) __builtin_amdgcn_s_sleep(16);
+            else if (DE_V6_IDLE_BACKOFF == 2 || idle < 64u) __builtin_amdgcn_s_sleep(DE_V6_IDLE_BACKOFF == 2 ? 32 : 48);
+            else __builtin_amdgcn_s_sleep(100);
         }
     }
 
@@ -562,7 +586,7 @@ struct Wave {
         int ready = 0;
         const uint32_t l = (uint32_t)lane_id();
         if (l < (uint32_t)NR && l != q) ready = (int)(ld_wg(tail(l)) - ld_wg(head(l)));
-        if (l == (uint32_t)Q_FREE && !primary_left) ready = 0;
+        if (l == (uint32_t)Q_FREE && !starters()) ready = 0;
         return __ballot(ready >= (int)A.elsewhere_min) != 0ull;
     }
 
@@ -628,7 +652,7 @@ struct Wave {
         push<Q_ST>(slot, q == (uint32_t)Q_ST); push<Q_GAS>(slot, q == (uint32_t)Q_GAS); push<Q_CLOUD>(slot, q == (uint32_t)Q_CLOUD); push<Q_EVENT>(slot, q == (uint32_t)Q_EVENT);
         push<Q_SURF>(slot, q == (uint32_t)Q_SURF); push<Q_SCFIN>(slot, q == (uint32_t)Q_SCFIN); push<Q_SURFFIN>(slot, q == (uint32_t)Q_SURFFIN);
         push<Q_FREE>(slot, !active);      // the slots claimed beyond the pool's end go home
-        if (n < 64u) primary_left = false;
+        if (n < 64u && lane_id() == 0) __hip_atomic_store(cw + 19, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // the pool is exhausted: nothing left to start
     }
 
     // ---- a straight-line stage: up to 64 slots per pass, one record per lane, written back in place
@@ -670,42 +694,49 @@ struct Wave {
     }
 
     // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
+#ifndef DE_V6_PRIMARY_BATCHES
+#define DE_V6_PRIMARY_BATCHES 1      // batches of 64 new paths per visit of the stage (experiment: 2, 4 — a visit costs a stage entry)
+#endif
     DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
         regions_begin();
-        if (w_lo >= w_hi) {
-            // Work items (64 = one screen tile x one sample; a tile's samples are consecutive) are handed out 256 per atomic from EIGHT counters,
-            // one per band of the launch's tiles, and a workgroup draws from the band of the XCD it runs on: the workgroups that share an L2
-            // render neighbouring tiles at the same time, the eight L2s hold eight different parts of the maps (one counter for the launch
-            // dealt a tile's samples to sixteen workgroups on all eight XCDs: every L2 held the same lines).  A band that has run out sends
-            // its workgroups to the next XCD's, so the launch ends as it did before.
-            const uint32_t nb = A.bands, spp = (uint32_t)a.spp_count, per = ((uint32_t)a.n_tiles + nb - 1u) / nb;
-            for (;;) {
-                if (w_tries >= nb) {
-                    primary_left = false;
-                    if (lane_id() == 0) add_wg(cw + 19, 0xffffffffu);      // one wave fewer that may still start paths (see schedule: the tail)
-                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    if (lane_id() == 0) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (STATS) t_drain = now;
-                    return;
-                }
-                const uint32_t band = (A.xcd + w_tries) % nb;
-                const uint32_t lo = min(band * per, (uint32_t)a.n_tiles) * 64u * spp, hi = min((band + 1u) * per, (uint32_t)a.n_tiles) * 64u * spp;
-                uint32_t w = 0;
-                if (lane_id() == 0) w = __hip_atomic_fetch_add(A.ctl + (G_WORKX + band) * DE_V6_CTL_STRIDE, 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w = uni(w);
-                if (w < hi - lo) { w_lo = lo + w; w_hi = min(lo + w + 256u, hi); break; }
-                w_tries++;
-            }
-        }
-        const uint32_t n = min(64u, w_hi - w_lo);
+#pragma nounroll
+        for (int b = 0; b < DE_V6_PRIMARY_BATCHES; ++b)
+            if (!primary_batch(a, fc)) break;
+        regions_end_flat(58);
+    }
+    // one batch: true when 64 paths were started (there may be more work and more free slots)
+    DE_DEV bool primary_batch(const RenderArgs& a, const FrameConsts& fc) {
+        // a wave-load of free slots FIRST, then the work items for them: a wave holds no claim from one call to the next (a failed slot claim used to keep the
+        // rest of a 256-item claim in the wave's registers across stage calls)
         uint32_t first = 0;
-        if (claim(Q_FREE, n, n, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return; }      // another wave was quicker: back to the scheduler
-        const uint32_t w = w_lo + (uint32_t)lane_id();
-        w_lo += n;
+        if (claim(Q_FREE, 64u, 64u, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return false; }      // another wave was quicker: back to the scheduler
+        uint32_t slot = take(Q_FREE, first + (uint32_t)lane_id());
+        if (__ballot(slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return false; }
+        // Work items (64 = one screen tile x one sample; a tile's samples are consecutive) are handed out 64 per atomic from EIGHT counters, one per band
+        // of the launch's tiles, and a workgroup draws from the band of the XCD it runs on: the workgroups that share an L2 render neighbouring tiles at
+        // the same time, the eight L2s hold eight different parts of the maps (one counter for the launch dealt a tile's samples to sixteen workgroups on
+        // all eight XCDs: every L2 held the same lines).  A band that has run out sends its workgroups to the next XCD's — cw[19] counts the bands this
+        // workgroup has left behind, for all its waves — so the launch ends as it did before.
+        const uint32_t nb = A.bands, spp = (uint32_t)a.spp_count, per = ((uint32_t)a.n_tiles + nb - 1u) / nb;
+        uint32_t tries = uni(ld_wg(cw + 19)), w0 = 0u, n = 0u;
+        for (;;) {
+            if (tries >= nb) {
+                primary_left = false;
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (lane_id() == 0) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            const uint32_t band = (A.xcd + tries) % nb;
+            const uint32_t lo = min(band * per, (uint32_t)a.n_tiles) * 64u * spp, hi = min((band + 1u) * per, (uint32_t)a.n_tiles) * 64u * spp;
+            uint32_t w = 0;
+            if (lane_id() == 0) w = __hip_atomic_fetch_add(A.ctl + (G_WORKX + band) * DE_V6_CTL_STRIDE, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w = uni(w);
+            if (w < hi - lo) { w0 = lo + w; n = min(64u, hi - lo - w); break; }
+            tries++;
+            if (lane_id() == 0) __hip_atomic_fetch_max(cw + 19, tries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const uint32_t w = w0 + (uint32_t)lane_id();
         const bool active = (uint32_t)lane_id() < n;
-        uint32_t slot = 0;
-        if (active) slot = take(Q_FREE, first + (uint32_t)lane_id());
-        if (__ballot(active && slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return; }
         acquire_wg();
         const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
         Path p;
@@ -743,8 +774,9 @@ struct Wave {
         push<Q_GAS>(slot, target == Q_GAS);
         push<Q_CLOUD>(slot, target == Q_CLOUD);
         push<Q_EVENT>(slot, target == Q_EVENT);
+        push<Q_FREE>(slot, !active);      // no work item came for these slots (the launch's last claims): they go home
         tick<R_PUSH>(0ull);
-        regions_end_flat(58);
+        return n == 64u && !aborted;
     }
 };
 
@@ -764,9 +796,9 @@ __global__ void v6_init_kernel(uint32_t* ctl, RenderArgs a, RenderArgs* dst) {
 // ---- the stage functions: NOT inlined into the kernel — one register allocation per stage (see "Geometry").  A stage function builds
 // its view of the wave from LDS, runs the stage until its ring is dry (or it hands its records back) and returns to the scheduler.
 #define DE_V6_STAGE template <bool CLAMP, bool STATS> static __device__ __attribute__((noinline)) void
-DE_V6_STAGE v6_stage_st(bool primary_left) {
+DE_V6_STAGE v6_stage_st() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     const FrameConsts& fc = *W.A.fc;
     const float MAX_RAY_DIST = (float)(6371e3 * 10.0);
@@ -775,44 +807,44 @@ DE_V6_STAGE v6_stage_st(bool primary_left) {
     StStage<CLAMP> st{a.topo, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST, 0.0f, 0};
     W.template run_loop<Q_ST>(st, Targets<Q_GAS, Q_CLOUD, Q_EVENT, Q_SURFFIN>{});
 }
-DE_V6_STAGE v6_stage_gas(bool primary_left) {
+DE_V6_STAGE v6_stage_gas() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     GasStage st{uni_ptr(a.nodes), uni_ptr(a.dens_table)};
     W.template run_loop<Q_GAS>(st, Targets<Q_CLOUD, Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
 }
-DE_V6_STAGE v6_stage_cloud(bool primary_left) {
+DE_V6_STAGE v6_stage_cloud() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     CloudStage<CLAMP> st{uni_tex(a.clouds)};
     W.template run_loop<Q_CLOUD>(st, Targets<Q_EVENT, Q_SCFIN, Q_SURFFIN>{});
 }
-DE_V6_STAGE v6_stage_event(bool primary_left) {
+DE_V6_STAGE v6_stage_event() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     const FrameConsts& fc = *W.A.fc;
     W.template run_flat<Q_EVENT>([&](Path& p, const ColdAt& cold) { return wf::event_body<CLAMP>(a, fc, cold, p); }, Targets<Q_GAS, Q_CLOUD, Q_SCFIN, Q_SURF>{});
 }
-DE_V6_STAGE v6_stage_surf(bool primary_left) {
+DE_V6_STAGE v6_stage_surf() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     const FrameConsts& fc = *W.A.fc;
     W.template run_flat<Q_SURF>([&](Path& p, const ColdAt& cold) { return wf::surf_body<CLAMP>(a, fc, cold, p); }, Targets<Q_ST>{});
 }
-DE_V6_STAGE v6_stage_scfin(bool primary_left) {
+DE_V6_STAGE v6_stage_scfin() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     const FrameConsts& fc = *W.A.fc;
     W.template run_flat<Q_SCFIN>([&](Path& p, const ColdAt& cold) { return wf::scfin_body(a, fc, cold, p); }, Targets<Q_ST>{});
 }
-DE_V6_STAGE v6_stage_surffin(bool primary_left) {
+DE_V6_STAGE v6_stage_surffin() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     const RenderArgs& a = *W.A.ra;
     W.template run_flat<Q_SURFFIN>([&](Path& p, const ColdAt& cold) { return wf::surffin_body(a, cold, p); }, Targets<Q_ST>{});
 }
@@ -820,16 +852,23 @@ DE_V6_STAGE v6_stage_surffin(bool primary_left) {
 // TAIL = false: the launch that starts a frame's paths (level 0).  TAIL = true: a tail launch — the same scheduler and stage functions, its new
 // paths are the previous level's pool (its own kernel name, so that a kernel trace tells the two apart).
 // the tail's two record movers, out of line like the stages (inlined they cost the kernel's own body — the scheduler and the new paths — its registers)
-DE_V6_STAGE v6_stage_export(bool primary_left) {
+DE_V6_STAGE v6_stage_export() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(primary_left);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     W.run_export(Targets<Q_ST, Q_GAS, Q_CLOUD, Q_EVENT, Q_SURF, Q_SCFIN, Q_SURFFIN>{});
 }
-template <bool CLAMP, bool STATS> static __device__ __attribute__((noinline)) bool v6_stage_import() {      // false: the pool is exhausted
+DE_V6_STAGE v6_stage_import() {
     using namespace bs;
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
     W.run_import();
-    return W.primary_left;
+}
+// new paths (TAIL = false launches): out of line as well — the kernel's own body is the scheduler loop and nothing else
+DE_V6_STAGE v6_stage_primary() {
+    using namespace bs;
+    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
+    const RenderArgs& a = *wf::opaque_ptr(W.A.ra);
+    const FrameConsts& fc = *wf::opaque_ptr(W.A.fc);
+    W.run_primary(a, fc);
 }
 
 template <bool CLAMP, bool STATS, bool TAIL>
@@ -840,7 +879,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         const uint32_t q = i / DE_V6_CAP, k = i % DE_V6_CAP;
         s_rings[i] = (uint16_t)((q == (uint32_t)Q_FREE && k < DE_V6_P) ? cell_full(0u, k) : cell_empty(0u));
     }
-    if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : (threadIdx.x == 19u ? (uint32_t)DE_V6_WAVES : 0u);
+    if (threadIdx.x < 32u) s_cw[threadIdx.x] = (threadIdx.x == 8u + (uint32_t)Q_FREE) ? DE_V6_P : 0u;      // ([19]: image bands this workgroup has left behind, 0 at the start)
     if (threadIdx.x < 64u) { s_node_val[threadIdx.x] = A.ra->node_val[threadIdx.x]; s_stats[threadIdx.x] = 0ull; }
     if (threadIdx.x == 0u) {
         Cfg c;
@@ -857,10 +896,13 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
     }
     __syncthreads();
     if (!TAIL && threadIdx.x == 0u) __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(A.ctl + G_T_START * DE_V6_CTL_STRIDE), (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter(true);
-    W.t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-
+    // The scheduler loop keeps NOTHING live across a stage call (statistics builds: the time stamp): the stage functions preserve no register (build.py:
+    // -enable-ipra), so every value held here would be a scratch store and a load per stage entry, 13.9 M times per BASELINE cfg2 frame.  The wave's view of the
+    // workgroup is rebuilt from LDS in every round (the few configuration words schedule() reads).
+    unsigned long long t_mark = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (;;) {
+        Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
+        W.t_mark = t_mark;
 #ifdef DE_V6_UNI_SWITCH
         const int s = __builtin_amdgcn_readfirstlane(W.schedule());      // wave-uniform by construction: said so, the dispatch below is scalar compares instead of an exec-masked branch tree
 #else
@@ -870,34 +912,28 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
         if (s == Q_EXIT) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (lane_id() == 0) __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(A.ctl + G_T_END * DE_V6_CTL_STRIDE), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (STATS && W.t_drain) W.stat(ST_DRAIN, now - W.t_drain);
+            if (STATS) {      // the wave's drain: from the launch's first "no work item left" to this wave's exit
+                const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(A.ctl + G_T_EXHAUSTED * DE_V6_CTL_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t0 != ~0ull && now > t0) W.stat(ST_DRAIN, now - t0);
+            }
             break;
         }
         if (STATS && s < NQ) W.stat(ST_ENTRY_Q + s, 1);
         switch (s) {
-        case Q_ST: v6_stage_st<CLAMP, STATS>(W.primary_left); W.template mark<Q_ST>(); break;
-        case Q_GAS: v6_stage_gas<CLAMP, STATS>(W.primary_left); W.template mark<Q_GAS>(); break;
-        case Q_CLOUD: v6_stage_cloud<CLAMP, STATS>(W.primary_left); W.template mark<Q_CLOUD>(); break;
-        case Q_EVENT: v6_stage_event<CLAMP, STATS>(W.primary_left); W.template mark<Q_EVENT>(); break;
-        case Q_SURF: v6_stage_surf<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURF>(); break;
-        case Q_SCFIN: v6_stage_scfin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SCFIN>(); break;
-        case Q_SURFFIN: v6_stage_surffin<CLAMP, STATS>(W.primary_left); W.template mark<Q_SURFFIN>(); break;
-        case Q_EXPORT: v6_stage_export<CLAMP, STATS>(W.primary_left); W.template mark<-1>(); break;
-        default: {
-            if (TAIL) {
-                if (!v6_stage_import<CLAMP, STATS>()) {
-                    W.primary_left = false;
-                    if (lane_id() == 0) add_wg(s_cw + 19, 0xffffffffu);
-                    if (STATS) W.t_drain = __builtin_amdgcn_s_memrealtime();
-                }
-            } else {
-                const RenderArgs& a = *wf::opaque_ptr(W.A.ra);
-                const FrameConsts& fc = *wf::opaque_ptr(W.A.fc);
-                W.run_primary(a, fc);
-            }
+        case Q_ST: v6_stage_st<CLAMP, STATS>(); W.template mark<Q_ST>(); break;
+        case Q_GAS: v6_stage_gas<CLAMP, STATS>(); W.template mark<Q_GAS>(); break;
+        case Q_CLOUD: v6_stage_cloud<CLAMP, STATS>(); W.template mark<Q_CLOUD>(); break;
+        case Q_EVENT: v6_stage_event<CLAMP, STATS>(); W.template mark<Q_EVENT>(); break;
+        case Q_SURF: v6_stage_surf<CLAMP, STATS>(); W.template mark<Q_SURF>(); break;
+        case Q_SCFIN: v6_stage_scfin<CLAMP, STATS>(); W.template mark<Q_SCFIN>(); break;
+        case Q_SURFFIN: v6_stage_surffin<CLAMP, STATS>(); W.template mark<Q_SURFFIN>(); break;
+        case Q_EXPORT: v6_stage_export<CLAMP, STATS>(); W.template mark<-1>(); break;
+        default:
+            if (TAIL) v6_stage_import<CLAMP, STATS>(); else v6_stage_primary<CLAMP, STATS>();
             W.template mark<7>();
-        } break;
+            break;
         }
+        t_mark = W.t_mark;
     }
     if (STATS) {
         __syncthreads();

@@ -7,8 +7,8 @@ import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (internal linkage since round 6 — the no-CSR optimisation of -mllvm -enable-ipra needs it —: _ZL...)
-STAGES = {"sphere trace": "_ZL11v6_stage_stILb0ELb0EEvb", "gas": "_ZL12v6_stage_gasILb0ELb0EEvb", "cloud": "_ZL14v6_stage_cloudILb0ELb0EEvb"}
-FLAT = {"event": "_ZL14v6_stage_eventILb0ELb0EEvb", "surface": "_ZL13v6_stage_surfILb0ELb0EEvb", "vol finish": "_ZL14v6_stage_scfinILb0ELb0EEvb", "surf finish": "_ZL16v6_stage_surffinILb0ELb0EEvb"}
+STAGES = {"sphere trace": "_ZL11v6_stage_stILb0ELb0EEvv", "gas": "_ZL12v6_stage_gasILb0ELb0EEvv", "cloud": "_ZL14v6_stage_cloudILb0ELb0EEvv"}
+FLAT = {"event": "_ZL14v6_stage_eventILb0ELb0EEvv", "surface": "_ZL13v6_stage_surfILb0ELb0EEvv", "vol finish": "_ZL14v6_stage_scfinILb0ELb0EEvv", "surf finish": "_ZL16v6_stage_surffinILb0ELb0EEvv"}
 
 
 def mid_scratch(lines):
