@@ -64,7 +64,7 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
         out.append("* frames in the trace: %d (one de_accumulate(64) call each, displayed after it); first render-kernel start to last render-kernel end, median: **%.2f ms** (min %.2f, max %.2f)"
                    % (len(spans), kernel_ms, min(spans), max(spans)))
         if n_primary: out.append("* a frame = %d batches side by side, each: the wavefront pipeline's stage kernels for the first vertex rounds + render_kernel_v2 as finisher of the surviving paths" % batches)
-        else: out.append("* a frame = one launch of the persistent kernel (the per-CU stage scheduler, render_kernel_v6.hip, unless a kernel variant was forced) + its tail launch (`v6_kernel<.., true>`: 64 workgroups that finish the paths the frame's workgroups exported)")
+        else: out.append("* a frame = one launch of the persistent kernel (the per-CU stage scheduler, render_kernel_v6.hip, unless a kernel variant was forced) + its tail launch (`v6_kernel<.., true>`: 64 workgroups that finish the paths the frame's workgroups exported).  NOTE: these passes run one frame at a time (`--sync-frames`, one launch slot), so no launch has a successor queued behind it, every workgroup decides to FINISH IN PLACE and the tail launch imports nothing: the counters are those of a frame rendered alone; the export / import path the timed region of bench.py uses (frames back to back) is measured by the `_tail` passes when present (`DE_V6_TAIL_ALONE=1`: export regardless)")
         rsum = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in trace if RENDER.search(r["Kernel_Name"])) / 1e6 / max(n_display, 1)
         out.append("* sum of the render kernels' own durations per displayed frame: %.1f ms%s" % (rsum, " (the batches overlap)" if n_primary else " (includes the bench's parity and counting launches)"))
         out.append("")
@@ -151,10 +151,35 @@ def main(tag, workload="1920x1080_64spp_q2", write_json="json"):
                            "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "valu_lane_utilisation": lane,
                            "salu_insts_per_launch": means.get("SQ_INSTS_SALU"), "source_sha16": source_sha16(),
                            "note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), summed over every render kernel of a frame (one "
-                                   "de_accumulate(64) call: one v6_kernel launch and its tail launch under the default variant); read bytes = 2 x FETCH_SIZE (a request "
+                                   "de_accumulate(64) call: one v6_kernel launch and its tail launch under the default variant — profiled one frame at a time, so the launch finishes in place and the tail launch imports nothing); read bytes = 2 x FETCH_SIZE (a request "
                                    "moves a 128-B line and is tallied as 64 B: profiles/r2_fetch_calibration). L2-miss traffic at the fabric: "
                                    "Infinity-Cache hits are included"},
                           f, indent=1)
+    # the same frame with the tail chain exporting (profile_gpu.sh: DE_V6_TAIL_ALONE=1 passes) — the path frames back to back take
+    tstats = read_csvs(os.path.join(root, "tail_stats", "**", "*kernel_stats.csv"))
+    if tstats:
+        out += ["", "## The tail chain exporting (`DE_V6_TAIL_ALONE=1`: what frames back to back run; one frame at a time here)", ""]
+        for r in sorted(tstats, key=lambda r: -float(r.get("TotalDurationNs", 0))):
+            if "v6_kernel" in r["Name"]:
+                out.append("* `%s`: %s launches, average %.3f ms" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6))
+        tp = defaultdict(float)
+        for d in sorted(glob.glob(os.path.join(root, "tail_pmc_*"))):
+            rows = [r for r in read_csvs(os.path.join(d, "**", "*counter_collection.csv")) if "v6_kernel" in r.get("Kernel_Name", "")]
+            disp = defaultdict(dict)
+            for r in rows:
+                disp[r["Dispatch_Id"]]["k"] = r["Kernel_Name"]
+                disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            names = {k for v in disp.values() for k in v if k != "k"}
+            for name in names:
+                frame_vals = [v.get(name, 0.0) for v in disp.values() if ", false>" in v["k"]]
+                big = [x for x in frame_vals if x >= 0.5 * max(frame_vals)]                      # the 64-spp launches
+                tail_vals = [v.get(name, 0.0) for v in disp.values() if ", true>" in v["k"]]
+                nt = max(len(big), 1)
+                tp[name] = sum(big) / nt + sum(sorted(tail_vals)[-len(big):]) / nt       # a frame = its launch + its tail launch
+        if tp:
+            out.append("* per frame (frame launch + tail launch): WRITE_SIZE %.1f GB, 2 x FETCH_SIZE %.1f GB, VALU %.4g, SALU %.4g wave-instructions, lane utilisation %.3f"
+                       % (tp.get("WRITE_SIZE", 0) * 1024 / 1e9, 2 * tp.get("FETCH_SIZE", 0) * 1024 / 1e9, tp.get("SQ_INSTS_VALU", 0), tp.get("SQ_INSTS_SALU", 0),
+                          tp.get("SQ_THREAD_CYCLES_VALU", 0) / max(64.0 * tp.get("SQ_ACTIVE_INST_VALU", 1), 1)))
     os.makedirs("profiles", exist_ok=True)
     with open(os.path.join("profiles", tag + "_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
