@@ -47,7 +47,7 @@ def main():
         L.append("| %s | %d | %.1f %% | %s | %d | %.2f |" % (nm, st[k], 100.0 * st[8 + k] / max(tot, 1), lu, trips, st[8 + k] * 0.01 / max(trips, 1)))
     L.append("| scheduler | | %.1f %% | idle rounds %d, stage entries %d, failed free-slot claims %d | | |" % (100.0 * st[19] / max(tot, 1), st[16], st[17], st[18]))
     if any(st[24:31]):
-        L += ["", "Stage entries (calls of the stage function; each saves and restores the callee-saved registers through scratch and re-reads the configuration): "
+        L += ["", "Stage entries (calls of the stage function; each re-reads its configuration from LDS; until round 6 it also saved and restored up to 24 callee-saved VGPRs through scratch): "
               + ", ".join("%s %d (%.0f records per entry)" % (STAGES[k], st[24 + k], st[k] / max(st[24 + k], 1)) for k in range(7)) + "."]
     L += ["", "Yields: %d, handing back %d records (%.1f %% of the loop stages' record hops).  Drain: %.2f ms per wave between the end of the work items and the wave's exit."
           % (st[20], st[21], 100.0 * st[21] / max(st[0] + st[1] + st[2], 1), st[22] * 1e-5 / max(1, 12 * 512)), ""]
