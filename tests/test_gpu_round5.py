@@ -76,11 +76,6 @@ def test_sample_partition_with_an_empty_share(Renderer, lut_arrays):
     r.close()
 
 
-def _ordered_reference(n):
-    rng = np.random.default_rng(5)
-    return [rng.standard_normal(n).astype(np.float32) * np.float32(10.0 ** rng.integers(-3, 4)) for _ in range(4)]
-
-
 @pytest.mark.timeout(600)
 def test_library_ordered_reduce_with_one_rank(Renderer):
     """de_reduce_ordered through a 1-rank communicator of the library (RCCL refuses two ranks on one device): the root's own buffer is the
