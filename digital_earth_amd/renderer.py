@@ -460,9 +460,9 @@ class Renderer:
         check(self._lib.de_enable_counters(self._h, 1 if on else 0))
 
     def set_kernel_variant(self, variant):
-        """4 = automatic (default): large launches run their first vertex rounds in the wavefront pipeline and finish in the
-        state machine; 2 = wave-level state machine only; 3 = wavefront pipeline (all rounds unless DE_V3_DEPTHS); 1 = per-lane
-        loops.  Identical results, bit for bit."""
+        """4 = automatic (default): a call of at least 4096 paths runs the per-CU stage scheduler (render_kernel_v6: one persistent launch, + a small
+        tail launch for big calls), smaller calls and counting launches the wave-level state machine; 2 / 6 = that kernel for every call.  1, 3, 5
+        (per-lane loops, wavefront pipeline, HBM-queue scheduler) exist in the legacy library only.  Identical results, bit for bit."""
         check(self._lib.de_set_kernel_variant(self._h, int(variant)))
 
     def set_memory_budget(self, n_bytes):
