@@ -20,9 +20,9 @@ DEPS_LEGACY = DEPS + [os.path.join("legacy", f) for f in ("render_kernel_v3.hip"
 # scheduler loop only).  Without it every stage entry saved and restored up to 24 callee-saved VGPRs through scratch: 48 scratch operations x 13.9 M stage
 # entries per BASELINE cfg2 frame = 140 GB of fabric traffic (a third of all of it) for values nobody keeps.  -fno-optimize-sibling-calls keeps the `tail`
 # marker off the calls (the optimisation refuses tail-called functions).  Measured, same box: cfg2 104.7 -> 100.9 ms per step, WRITE_SIZE 94.6 -> 49.2 GB,
-# L2 misses 2.61e9 -> 2.03e9 per frame (profiles/experiments/README.md, round 6).  -DDE_V6_UNI_SWITCH: the scheduler's answer dispatched with scalar compares.
+# L2 misses 2.61e9 -> 2.03e9 per frame (profiles/experiments/README.md, round 6).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",
-         "-shared", "-Wno-unused-value", "-mllvm", "-enable-ipra", "-fno-optimize-sibling-calls", "-DDE_V6_UNI_SWITCH"]
+         "-shared", "-Wno-unused-value", "-mllvm", "-enable-ipra", "-fno-optimize-sibling-calls"]
 
 
 def needs_build():

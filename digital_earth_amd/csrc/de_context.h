@@ -79,7 +79,7 @@ struct de_ctx {
     int last_v6_slot = -1;          // the slot of the newest render_kernel_v6 launch (the tail's "has a successor on another slot" word is about v6 launches only)
     int cu_withhold = 0;            // de_tuning.v6_cu_withhold: CUs per XCD the launch slots' streams may NOT use (hipExtStreamCreateWithCUMask), so that small kernels of
                                     // the context stream (collective, accumulate, display) find a free CU while persistent workgroups own the others; 0 = plain streams
-    float* d_standin = nullptr;     // second operand of de_debug_standin_reduce (zeros, [H][W][3])
+    float* d_standin = nullptr;     // de_debug_standin_reduce: its second operand (zeros), its output and its copy target, [3][H][W][3]
     hipEvent_t ev_standin[16][2] = {};   // the last 16 stand-in collectives: de_last_reduce_ms answers their MEAN queue-to-finish time (frames in flight: no host wait per frame)
     unsigned standin_count = 0;
     bool last_reduce_standin = false;

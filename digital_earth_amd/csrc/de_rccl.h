@@ -243,17 +243,16 @@ int de_debug_standin_reduce(de_ctx* c, int extra_copies) {
     if (rc) return rc;
     const size_t count = (size_t)c->W * c->H * 3;
     if (!c->d_standin) {
-        HIP_TRY(hipMalloc(&c->d_standin, count * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(c->d_standin, 0, count * sizeof(float), c->stream));
+        // operand, output and copy target of its own ([3][H][W][3]): never the assembled buffer a progressive display may be reading
+        HIP_TRY(hipMalloc(&c->d_standin, 3 * count * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->d_standin, 0, 3 * count * sizeof(float), c->stream));
     }
-    rc = ordered_root_buffers(c, extra_copies > 0 ? 2 : 1, true);
-    if (rc) return rc;
     const unsigned e = c->standin_count % 16u;
     if (!c->ev_standin[e][0]) { HIP_TRY(hipEventCreate(&c->ev_standin[e][0])); HIP_TRY(hipEventCreate(&c->ev_standin[e][1])); }
     HIP_TRY(hipEventRecord(c->ev_standin[e][0], c->stream));
-    for (int k = 0; k < extra_copies; ++k) HIP_TRY(hipMemcpyAsync(c->d_gather, c->d_standin, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    for (int k = 0; k < extra_copies; ++k) HIP_TRY(hipMemcpyAsync(c->d_standin + 2 * count, c->d_standin, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     OrderedSumArgs o;
-    o.part[0] = c->d_hdr; o.part[1] = c->d_standin; o.out = c->d_assembled; o.n_parts = 2; o.n4 = count / 4; o.n = count;
+    o.part[0] = c->d_hdr; o.part[1] = c->d_standin; o.out = c->d_standin + count; o.n_parts = 2; o.n4 = count / 4; o.n = count;
     hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)c->n_cus * 8u), dim3(256), 0, c->stream, o);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_standin[e][1], c->stream));

@@ -168,11 +168,7 @@ __shared__ uint32_t s_cfg[40];
 
 // (the lane's index from the execution-mask counters, not from threadIdx: a stage function that never asks for the work-item id does not receive it — one VGPR
 // more for its allocator, and the scheduler loop has no packed id to keep alive, i.e. to reload from scratch, for every stage call)
-#ifdef DE_V6_LANE_TID
-DE_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
-#else
 DE_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-#endif
 DE_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // What a stage reads of the launch (map descriptors, table pointers, frame constants) arrives through a pointer the optimiser cannot see through
 // — as flat loads into VECTOR registers, although every lane gets the same value.  Broadcast to scalar registers: a map's seven dwords in
@@ -464,13 +460,10 @@ struct Wave {
             // An idle wave backs off: a scheduler round is ~100 instructions, and in a launch's drain — most of a one-sample launch — eleven of a workgroup's twelve
             // waves are idle: at one round per ~0.5 us they took a third of the instructions such a launch executes, from the working waves of the launches that
             // overlap with it.  With twelve waves waking at different times a record still waits only a fraction of one sleep.
-#ifndef DE_V6_IDLE_BACKOFF
-#define DE_V6_IDLE_BACKOFF 1
-#endif
-            if (!DE_V6_IDLE_BACKOFF) { if (idle < 16u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16); }
-            else if (idle < 8u) __builtin_amdgcn_s_sleep(2);
+            // (no back-off, or one capped at s_sleep 32: within noise of this on every workload measured — profiles/experiments/README.md, round 6)
+            if (idle < 8u) __builtin_amdgcn_s_sleep(2);
             else if (idle < 24u) __builtin_amdgcn_s_sleep(16);
-            else if (DE_V6_IDLE_BACKOFF == 2 || idle < 64u) __builtin_amdgcn_s_sleep(DE_V6_IDLE_BACKOFF == 2 ? 32 : 48);
+            else if (idle < 64u) __builtin_amdgcn_s_sleep(48);
             else __builtin_amdgcn_s_sleep(100);
         }
     }
@@ -694,24 +687,19 @@ struct Wave {
     }
 
     // ---- new paths: 64 work items = the 64 pixels of one screen tile for one sample; the primary sphere trace runs here (coherent rays)
-#ifndef DE_V6_PRIMARY_BATCHES
-#define DE_V6_PRIMARY_BATCHES 1      // batches of 64 new paths per visit of the stage (experiment: 2, 4 — a visit costs a stage entry)
-#endif
-    DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {
+    DE_DEV void run_primary(const RenderArgs& a, const FrameConsts& fc) {      // (two or four batches per visit: no gain — profiles/experiments/README.md, round 6)
         regions_begin();
-#pragma nounroll
-        for (int b = 0; b < DE_V6_PRIMARY_BATCHES; ++b)
-            if (!primary_batch(a, fc)) break;
+        primary_batch(a, fc);
         regions_end_flat(58);
     }
-    // one batch: true when 64 paths were started (there may be more work and more free slots)
-    DE_DEV bool primary_batch(const RenderArgs& a, const FrameConsts& fc) {
+    // one batch of 64 new paths
+    DE_DEV void primary_batch(const RenderArgs& a, const FrameConsts& fc) {
         // a wave-load of free slots FIRST, then the work items for them: a wave holds no claim from one call to the next (a failed slot claim used to keep the
         // rest of a 256-item claim in the wave's registers across stage calls)
         uint32_t first = 0;
-        if (claim(Q_FREE, 64u, 64u, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return false; }      // another wave was quicker: back to the scheduler
+        if (claim(Q_FREE, 64u, 64u, &first) == 0u) { stat(ST_CLAIMFAIL, 1); return; }      // another wave was quicker: back to the scheduler
         uint32_t slot = take(Q_FREE, first + (uint32_t)lane_id());
-        if (__ballot(slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return false; }
+        if (__ballot(slot == DE_V6_EMPTY) != 0ull) { raise(ERR_ENTRY_TIMEOUT); return; }
         // Work items (64 = one screen tile x one sample; a tile's samples are consecutive) are handed out 64 per atomic from EIGHT counters, one per band
         // of the launch's tiles, and a workgroup draws from the band of the XCD it runs on: the workgroups that share an L2 render neighbouring tiles at
         // the same time, the eight L2s hold eight different parts of the maps (one counter for the launch dealt a tile's samples to sixteen workgroups on
@@ -746,24 +734,7 @@ struct Wave {
             wf::new_path(a, fc, bs::s_node_val, w, p);
             const float t = wf::sphere_trace<CLAMP>(a, p, fc.land_height_scale, DE_PLANET_R + de_max(fc.land_height_scale, 0.0f) + 8100.0f, MAX_RAY_DIST);
             target = wf::after_sphere_trace(p, t, MAX_RAY_DIST);
-        }
-#if defined(DE_V6_PRIMARY_GAS) && DE_V6_PRIMARY_GAS > 0
-        // EXPERIMENT (VERDICT r5 #1a, its most favourable case): the first DE_V6_PRIMARY_GAS steps of the primary ray's gas segment run HERE, where all 64 lanes
-        // start a gas segment at once, so that a segment that ends within them never becomes a record of the gas stage; what is left goes on as a SUSPENDED
-        // record (the yield path's format: GasStage::suspend / restore, bit for bit).
-        {
-            GasStage gs{uni_ptr(a.nodes), uni_ptr(a.dens_table)};
-            bool g_busy = active && target == Q_GAS, g_fin = false;
-            if (g_busy) gs.begin(p);
-#pragma nounroll
-            for (int k = 0; k < DE_V6_PRIMARY_GAS && __ballot(g_busy) != 0ull; ++k) {
-                if (g_busy && gs.step(p)) { g_busy = false; g_fin = true; }
-            }
-            if (g_fin) target = gs.finish(p);
-            if (g_busy) { gs.suspend(p, cold + slot); p.meta |= 0x80000000u; }
-        }
-#endif
-        if (active) {
+            // (the first gas steps of the primary ray run inline here — all 64 lanes start a gas segment at once —: bit-identical, flat; profiles/experiments/r6_primary_gas.patch)
             store_rec(rec, slot, p);
             cold[slot].pad0 = wf::asf(p.pid);
         }
@@ -776,7 +747,6 @@ struct Wave {
         push<Q_EVENT>(slot, target == Q_EVENT);
         push<Q_FREE>(slot, !active);      // no work item came for these slots (the launch's last claims): they go home
         tick<R_PUSH>(0ull);
-        return n == 64u && !aborted;
     }
 };
 
@@ -903,11 +873,7 @@ v6_kernel(bs::Args A, const FrameConsts* fcp) {
     for (;;) {
         Wave<CLAMP, STATS> W = Wave<CLAMP, STATS>::enter();
         W.t_mark = t_mark;
-#ifdef DE_V6_UNI_SWITCH
         const int s = __builtin_amdgcn_readfirstlane(W.schedule());      // wave-uniform by construction: said so, the dispatch below is scalar compares instead of an exec-masked branch tree
-#else
-        const int s = W.schedule();
-#endif
         W.template mark<-1>();
         if (s == Q_EXIT) {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();

@@ -7,6 +7,6 @@ set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/build/ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wno-unused-value ${DE_AB_BASE_FLAGS--mllvm -enable-ipra -fno-optimize-sibling-calls -DDE_V6_UNI_SWITCH} "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wno-unused-value ${DE_AB_BASE_FLAGS--mllvm -enable-ipra -fno-optimize-sibling-calls} "$@" \
   $ROOT/digital_earth_amd/csrc/de_api.hip $ROOT/digital_earth_amd/csrc/de_fast.hip -o $ROOT/build/ab/$NAME.so
 echo built $ROOT/build/ab/$NAME.so

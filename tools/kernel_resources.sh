@@ -2,7 +2,7 @@
 # usage: tools/kernel_resources.sh [regex]  -> one line per kernel: VGPRs, SGPRs, spills, scratch, occupancy, LDS, code bytes (hipcc cross-compiles: no GPU needed)
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 cd $REPO/digital_earth_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -mllvm -enable-ipra -fno-optimize-sibling-calls -DDE_V6_UNI_SWITCH ${DE_EXTRA_FLAGS} -S --cuda-device-only \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-value -mllvm -enable-ipra -fno-optimize-sibling-calls ${DE_EXTRA_FLAGS} -S --cuda-device-only \
   -Rpass-analysis=kernel-resource-usage de_api.hip -o /tmp/de_res.s 2> /tmp/de_res.txt
 python3 - "$1" <<'PY'
 import re, sys
