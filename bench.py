@@ -12,6 +12,12 @@ over the ranks (tile partition), so scaling is "strong".  Rank 0 prints ONE JSON
 
 Workload (BASELINE.json configs[1]): 1920x1080, 64 spp, full spectral Rayleigh+Mie+O3+clouds, quality-2 maps
 (21600x10800 / 16200x8100, synthetic stand-ins: the reference ships no maps), default camera and sun.
+
+`--config cfg2|cfg3|cfg4|cfg5` runs any BASELINE config by name (size, sample count, the reference's camera preset, cloud-heavy maps, progressive interval;
+the line's `metric` names it).  The default 1-GPU run adds, after the timed region: `other_configs` (cfg3 / cfg4 / cfg5 for two steps each, the frame at the
+config's full sample count checked against the oracle on sparse tiles), `cpu_baseline` (the oracle on a bounded sample, all host threads) and `parity` (the
+full-size frame against the oracle's at matched seed).  One-GPU experiments for the N-rank path: `--simulate-world N` (rank 0's share, no collective),
+`--standin-collective COPIES` (a stand-in for the frame's collective where the reduce goes), `--cu-withhold n` (CUs per XCD left to the small kernels).
 """
 import argparse
 import json
