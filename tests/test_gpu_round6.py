@@ -203,3 +203,36 @@ def test_an_empty_share_reports_no_duration(Renderer):
     r.accumulate(2)                       # indices 4, 5: none = 3 (mod 4)
     assert r.last_accumulate_ms() == 0.0
     r.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("lag", [1, 2])
+def test_earth_viewer_frame_loop_pipelined(lag):
+    """EarthViewer.frame(pipelined=L): the reference's window loop (earth_viewer.py:203-317) with display and host copy of an iteration running while the next renders.
+    The images are those of the synchronous loop, L iterations later — through a slider that resets the framebuffer (sun angle), one that does not (exposure) and a
+    camera move; finish() hands out the rest."""
+    from digital_earth_amd.earth_viewer import EarthViewer
+    kw = dict(screen_res=(256, 128), texture_source="synthetic", texture_size=(1024, 512), seed=5)
+
+    def script(v, k):
+        if k == 3:
+            return dict(sun_angle=0.9)
+        if k == 5:
+            return dict(exposure=1.7)
+        if k == 6:
+            v.camera.rotate(0.01, 0.0)
+        return {}
+    a = EarthViewer(**kw)
+    sync = [a.frame(spp=1, **script(a, k)).copy() for k in range(9)]
+    b = EarthViewer(**kw)
+    got = [b.frame(spp=1, pipelined=lag, **script(b, k)) for k in range(9)]
+    assert all(x is None for x in got[:lag])
+    tail = b.renderer.fetch_pending(all_images=True)
+    assert len(tail) == lag
+    seq = [np.array(x) for x in got[lag:]] + tail
+    assert len(seq) == 9
+    for k in range(9):
+        assert (seq[k].view(np.uint32) == sync[k].view(np.uint32)).all(), k
+    assert sync[3].std() > 0 and not (sync[4] == sync[3]).all()      # the sun moved after iteration 3: iteration 4 starts a new accumulation
+    assert b.finish() is None
+    a.close(); b.close()
