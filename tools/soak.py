@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the shipped kernel: many frames back to back on one context — changing cameras, sample counts, seeds, partitions, calls in flight on every
-launch slot, the tail chain exporting whenever a call is queued behind another — and after every batch a fetch (where an aborted launch would surface as DE_ERR_HIP) and,
+launch slot, the tail chain exporting whenever a call is queued behind another, (round 6) pipelined fetches between the calls and CU-masked render streams switched on and off — and
+after every batch a fetch (where an aborted launch would surface as DE_ERR_HIP) and,
 for one frame of the batch, a second render of the same seed on a FRESH context with one launch per call: the two must agree bit for bit.
 
   python tools/soak.py [--minutes 3] [--width 1920 --height 1080]        -> a one-line summary per batch, a total at the end (exit code 1 on any mismatch)"""
@@ -39,8 +40,16 @@ def main():
         rng2 = np.random.default_rng(seed)
         setup(r)
         r.reset_framebuffer()
+        if batch % 7 == 3:                          # (round 6) now and then the render streams leave a CU per XCD alone: another grid size, recreated streams
+            t = r.tuning(); t.v6_cu_withhold = 1 - t.v6_cu_withhold; r.set_tuning(t)
+        lag = int(rng.integers(0, 4)) if batch % 3 == 0 else 0
         for n in calls:
             r.accumulate(n)                         # nothing waits in between: the calls queue up on all launch slots
+            if lag:
+                r.fetch_image(copy=False, lag=lag)  # (round 6) the pipelined window loop's display + host copy between the calls, up to three in flight
+        if lag:
+            shown = r.fetch_pending(copy=True)
+            assert shown is not None and np.isfinite(shown).all()
         got = r.fetch_hdr()                         # an aborted launch surfaces here
         frames += 1; paths += a.width * a.height * sum(calls) // part[1]
         line = "batch %3d  %-32s spp %-28s partition %d/%d  max %.3g" % (batch, preset, "+".join(map(str, calls)), part[0], part[1], float(got.max()))
