@@ -16,8 +16,6 @@ hipError_t create_slot_stream(de_ctx* c, hipStream_t* out) {
     for (int i = 0; i < keep && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
     return hipExtStreamCreateWithCUMask(out, (uint32_t)((n + 31) / 32), mask);
 }
-// CUs a render_kernel_v6 launch may fill
-int render_cus(const de_ctx* c) { return c->cu_withhold > 0 ? c->n_cus - 8 * c->cu_withhold : c->n_cus; }
 }  // namespace
 
 extern "C" {

@@ -297,10 +297,6 @@ struct Wave {
         }
         aborted = true;
     }
-    DE_DEV bool abort_seen() {      // the workgroup's own word: the workgroups share nothing but the work counter, the others finish their paths
-        if (!aborted && uni(ld_wg(cw + 16)) != 0u) aborted = true;
-        return aborted;
-    }
 
     // Can this workgroup still start paths?  cw[19] counts the image bands it has found exhausted (run_primary; a tail launch's import stores all ones when
     // the pool is): below the launch's band count, yes.  Monotonic, so a "no" is final — from then on the workgroup's population only falls.

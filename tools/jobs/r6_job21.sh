@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, GPU job 21: the kernel source with the experiment switches removed (same code) — the whole GPU suite, the profile of record again (the replayed counters are tied to a
+# round 6, GPU job 21 (run twice: after the experiment switches and after the last dead code were taken out of the source — same kernel code) — the whole GPU suite, the profile of record again (the replayed counters are tied to a
 # hash of the sources), the bench line
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r6_job21; mkdir -p $OUT
